@@ -1,0 +1,244 @@
+#!/usr/bin/env python3
+"""Benchmark of the hot path: 16 kHz PCM -> fbank/LFR/CMVN -> Paraformer-large SAN-M encoder (50 blocks).
+
+    python bench.py --gpus N --steps K --warmup W
+
+A step is one pass of frontend + encoder over one batch of 64 synthetic 30 s utterances per GPU (the
+per-GPU slice of BASELINE.json's "batch 512 sharded 64/GPU" configuration; inputs are resident in HBM
+before the timed region).  For N > 1 the launcher starts one rank per GPU; utterances are independent,
+so ranks exchange nothing on the data path: only a barrier and a MAX over ranks of the elapsed time.
+
+Rank 0 prints ONE JSON line.  Besides the contract fields it carries
+  roofline      : the dominant kernel (FFN1 GEMM, bf16 MFMA) priced against the dense bf16 MFMA peak from
+                  HIP-event timings taken inside this process,
+  roofline_fbank: the fbank kernel on 256 x 30 s (BASELINE.json configs[1]) priced against HBM peak,
+  cpu_baseline  : the CPU oracle (a port: the reference's own CPU stack is not installable offline)
+                  timed on a bounded sample on this host's cores,
+  stages        : per-kernel-kind time per step from the same event pass.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+SAMPLES = 480000          # 30 s @ 16 kHz
+T_FRAMES = 2998
+TP = 500
+MFMA_BF16_PEAK_TFLOPS = 2500.0   # dense bf16, MI355X
+HBM_PEAK_GBPS = 8000.0
+FBANK_BYTES_PER_UTT = 960000 + 959360   # int16 PCM in + fp32 log-mel out
+GEMM_FLOP_PER_UTT = 157.4e9             # QKV + out-proj + FFN over 50 layers at T' = 500
+ALL_FLOP_PER_UTT = 183.2e9              # + attention matmuls + FSMN
+
+
+def gemm_flops(m, n, k):
+    return 2.0 * m * n * k
+
+
+def cpu_baseline(sd, n_clips: int):
+    """Times the CPU oracle on n_clips 30 s utterances (frontend in numpy float64, encoder in torch fp32)."""
+    from oracle import fbank_oracle as fo
+    from oracle import sanm_oracle as so
+    from toolbox_for_asr_and_tts_amd.synth import bench_pcm
+
+    pcm = bench_pcm(n_clips, SAMPLES, seed=99)
+    cfg = so.SanmConfig(num_blocks=50)
+    t0 = time.perf_counter()
+    feats, lens = fo.frontend(pcm, [SAMPLES] * n_clips)
+    t1 = time.perf_counter()
+    so.encoder_forward(torch.from_numpy(feats).float(), torch.from_numpy(lens), sd, cfg)
+    t2 = time.perf_counter()
+    return {
+        "value": n_clips / (t2 - t0),
+        "unit": "utt/s",
+        "cores": int(torch.get_num_threads()),
+        "kind": "port",
+        "sample": f"{n_clips} x 30 s utterances through oracle/fbank_oracle.py (numpy f64, 1 thread) and "
+                  f"oracle/sanm_oracle.py (torch fp32, {torch.get_num_threads()} threads), 50 blocks",
+        "frontend_s": t1 - t0,
+        "encoder_s": t2 - t1,
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=64, help="utterances per GPU per step")
+    ap.add_argument("--fbank-batch", type=int, default=256)
+    ap.add_argument("--cpu-clips", type=int, default=2)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-stages", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist  # RCCL; used for the barrier and the MAX over ranks only
+
+        dist.init_process_group("nccl", device_id=dev)
+
+    import toolbox_for_asr_and_tts_amd as pkg
+    from toolbox_for_asr_and_tts_amd.synth import bench_pcm, encoder_state_dict
+
+    sd = encoder_state_dict(num_blocks=50, seed=0)
+    eng = pkg.AsrEngine(batch=args.batch, max_samples=SAMPLES, state_dict=sd)
+    pcm = torch.from_numpy(bench_pcm(args.batch, SAMPLES, seed=1234 + rank)).to(dev)
+    lens = torch.full((args.batch,), SAMPLES, dtype=torch.int32, device=dev)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        eng.run(pcm, lens)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        eng.run(pcm, lens)
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        dist.barrier()
+    out_ok = bool(torch.isfinite(eng.out).all().item())
+
+    result = None
+    if rank == 0:
+        utts = world * args.batch * args.steps
+        value = utts / elapsed
+        result = {
+            "metric": "utterances/sec (30 s @16 kHz) fbank+Paraformer encoder",
+            "value": value,
+            "unit": "utt/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "bf16",
+            "data": "synthetic",
+            "config": {
+                "workload": f"fbank+LFR+CMVN+SAN-M encoder (50 blocks, d=512), {args.batch} x 30 s int16 utterances "
+                            f"per GPU per step (BASELINE configs[3] slice: 64/GPU), random-init N(0,0.02) weights",
+                "batch_per_gpu": args.batch,
+                "global_batch": world * args.batch,
+                "parallelism": f"utterance-sharded x{world}, no collective",
+            },
+            "output_finite": out_ok,
+            "achieved_tflops_all": value * ALL_FLOP_PER_UTT / 1e12 / world,
+        }
+
+    if rank == 0 and not args.no_stages:
+        # ---- per-kernel HIP-event pass (same process, same inputs, after the timed region) ----------
+        eng.ctx.profile_begin(4096)
+        nprof = 3
+        for _ in range(nprof):
+            eng.run(pcm, lens)
+        prof = eng.ctx.profile_end()
+        stages = {k: {"launches_per_step": v[0] // nprof, "ms_per_step": v[1] / nprof} for k, v in prof.items()}
+        m = args.batch * TP
+        flops = {
+            "gemm_qkv": 49 * gemm_flops(m, 1536, 512) + gemm_flops(m, 1536, 560),
+            "gemm_out": 50 * gemm_flops(m, 512, 512),
+            "gemm_ffn1": 50 * gemm_flops(m, 2048, 512),
+            "gemm_ffn2": 50 * gemm_flops(m, 512, 2048),
+            "attention": 50 * args.batch * 4 * 2 * gemm_flops(TP, TP, 128),
+        }
+        for k, f in flops.items():
+            if k in stages:
+                stages[k]["tflops"] = f / (stages[k]["ms_per_step"] * 1e-3) / 1e12
+        result["stages"] = stages
+        gemm_ms = sum(stages[k]["ms_per_step"] for k in ("gemm_qkv", "gemm_out", "gemm_ffn1", "gemm_ffn2") if k in stages)
+        gemm_fl = sum(flops[k] for k in ("gemm_qkv", "gemm_out", "gemm_ffn1", "gemm_ffn2"))
+        result["gemm_mfma_util"] = gemm_fl / (gemm_ms * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS
+        if "gemm_ffn1" in stages:
+            st = stages["gemm_ffn1"]
+            ach = gemm_flops(m, 2048, 512) / (st["ms_per_step"] / st["launches_per_step"] * 1e-3) / 1e12
+            result["roofline"] = {
+                "kernel": "gemm_bf16_kernel<EPI_BF16_RELU> (FFN1: [32000 x 512] x [512 x 2048], bias + ReLU, bf16 out)",
+                "bound": "mfma",
+                "achieved": ach,
+                "peak": MFMA_BF16_PEAK_TFLOPS,
+                "unit": "TFLOP/s",
+                "frac": ach / MFMA_BF16_PEAK_TFLOPS,
+                "traffic": None,
+                "launch_us": 1e3 * st["ms_per_step"] / st["launches_per_step"],
+                "flop_per_launch": gemm_flops(m, 2048, 512),
+            }
+
+        # ---- fbank-only stage: 256 x 30 s -> 80-dim log-mel (HBM roofline) ---------------------------
+        fb = args.fbank_batch
+        del pcm
+        pcm_f = torch.from_numpy(bench_pcm(fb, SAMPLES, seed=4321)).to(dev)
+        lens_f = torch.full((fb,), SAMPLES, dtype=torch.int32, device=dev)
+        logmel = torch.empty((fb, T_FRAMES, 80), dtype=torch.float32, device=dev)
+        nfr = torch.empty((fb,), dtype=torch.int32, device=dev)
+        import ctypes as C
+
+        def fbank_once():
+            eng.ctx.check(eng.ctx.lib.asrfe_fbank(eng.ctx.handle, pcm_f.data_ptr(), 0, pcm_f.stride(0), lens_f.data_ptr(),
+                                                  fb, T_FRAMES, logmel.data_ptr(), nfr.data_ptr(),
+                                                  C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+
+        for _ in range(3):
+            fbank_once()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        reps = 20
+        e0.record()
+        for _ in range(reps):
+            fbank_once()
+        e1.record()
+        torch.cuda.synchronize()
+        us = 1e3 * e0.elapsed_time(e1) / reps
+        gbps = fb * FBANK_BYTES_PER_UTT / (us * 1e-6) / 1e9
+        result["roofline_fbank"] = {
+            "kernel": "fbank_kernel<int16, unfused> (256 x 30 s -> [256, 2998, 80] fp32 log-mel)",
+            "bound": "hbm",
+            "achieved": gbps,
+            "peak": HBM_PEAK_GBPS,
+            "unit": "GB/s",
+            "frac": gbps / HBM_PEAK_GBPS,
+            "traffic": None,
+            "launch_us": us,
+            "bytes_per_launch": fb * FBANK_BYTES_PER_UTT,
+            "utt_per_s": fb / (us * 1e-6),
+        }
+        del pcm_f, logmel
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        result["cpu_baseline"] = cpu_baseline(sd, args.cpu_clips)
+
+    if rank == 0:
+        print(json.dumps(result))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

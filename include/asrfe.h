@@ -1,0 +1,165 @@
+/*
+ * libasrfe - MI355X (gfx950) speech frontend + Paraformer SAN-M encoder, C ABI.
+ *
+ * The reference (terrense/toolbox-for-ASR-and-TTS) has no FFI of its own for this
+ * path: it calls Python objects of third-party packages.  Each entry point below
+ * names the Python-level interface it stands in for; reference citations are
+ * relative to /root/reference/.
+ *
+ *   funasr.AutoModel(...) / modelscope pipeline construction
+ *       voice-service/app/services/voice_interface.py:686-700, 832-841   -> asrfe_create,
+ *                                                                           asrfe_load_cmvn,
+ *                                                                           asrfe_load_encoder_weights
+ *   pipeline(wav, batch_size_s=..., ...) -> WavFrontend.forward(input[B,N], lengths[B])
+ *       voice_interface.py:2049-2053 (ASR), :1585-1590 (VAD), :1370-1374 (KWS)
+ *                                                                        -> asrfe_fbank,
+ *                                                                           asrfe_lfr_cmvn,
+ *                                                                           asrfe_frontend
+ *   ... -> SANMEncoder.forward(xs_pad[B,T',560], ilens[B])
+ *       voice_interface.py:2049-2053                                     -> asrfe_encoder_forward
+ *
+ * Conventions
+ *   - every function returns an int32 status (ASRFE_OK == 0, negative on error); no C++
+ *     exception crosses the boundary; asrfe_last_error() holds the detail text;
+ *   - all data pointers except the *_host ones are DEVICE pointers owned by the caller;
+ *     the library never frees caller memory and never allocates in the compute calls
+ *     (asrfe_fbank, asrfe_lfr_cmvn, asrfe_frontend, asrfe_encoder_forward): scratch
+ *     comes in through the workspace argument;
+ *   - compute calls are asynchronous with respect to the host and ordered on the HIP
+ *     stream passed as void* (a hipStream_t; NULL = the default stream);
+ *   - a context is bound to the device that was current in asrfe_create and is not
+ *     internally synchronised: one context per (process, device);
+ *   - PCM is mono 16 kHz, row b of a [B, pcm_stride] array holding pcm_lens[b] samples:
+ *     int16 (canonical, voice_interface.py:1997-2023) or float32 in [-1, 1) which is
+ *     multiplied by 32768 (voice_interface.py:1009-1010, 1046).
+ */
+#ifndef ASRFE_H
+#define ASRFE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ASRFE_OK 0
+#define ASRFE_ERR_BAD_ARG (-1)
+#define ASRFE_ERR_SHAPE (-2)
+#define ASRFE_ERR_HIP (-3)
+#define ASRFE_ERR_UNSUPPORTED_ARCH (-4)
+#define ASRFE_ERR_NOT_LOADED (-5)
+#define ASRFE_ERR_WORKSPACE (-6)
+
+#define ASRFE_PCM_I16 0
+#define ASRFE_PCM_F32 1
+
+#define ASRFE_DT_F32 0
+#define ASRFE_DT_BF16 1
+
+typedef struct asrfe_ctx asrfe_ctx;
+
+/* Frontend + encoder hyper-parameters (FunASR config.yaml: frontend_conf / encoder_conf). */
+typedef struct asrfe_config {
+    int32_t sample_rate;     /* 16000 */
+    int32_t frame_length;    /* samples per frame: 400 (25 ms)   - only 400 is built  */
+    int32_t frame_shift;     /* hop in samples:   160 (10 ms)   - only 160 is built  */
+    int32_t n_fft;           /* 512 */
+    int32_t n_mels;          /* 80  (<= 80) */
+    float preemph;           /* 0.97 */
+    float low_freq;          /* 20 Hz */
+    float high_freq;         /* 0 or negative: offset from Nyquist, Kaldi style */
+    int32_t window_type;     /* 0 hamming, 1 hanning, 2 povey, 3 rectangular */
+    int32_t lfr_m;           /* 7 */
+    int32_t lfr_n;           /* 6 */
+    int32_t enc_input_size;  /* 560 */
+    int32_t enc_output_size; /* 512 - only 512 is built */
+    int32_t enc_heads;       /* 4   - only d_k = 128 is built */
+    int32_t enc_linear_units;/* 2048 */
+    int32_t enc_num_blocks;  /* 50 (1 layer input_size->output_size + num_blocks-1 layers) */
+    int32_t enc_kernel_size; /* 11 */
+    int32_t enc_sanm_shift;  /* 0 */
+    float enc_ln_eps;        /* 1e-12 */
+} asrfe_config;
+
+/* One named host tensor of an encoder state_dict (FunASR key names without the "encoder." prefix). */
+typedef struct asrfe_tensor_desc {
+    const char* name;       /* e.g. "encoders.3.self_attn.linear_q_k_v.weight" */
+    const float* data_host; /* contiguous row-major float32 on the HOST */
+    int32_t ndim;
+    int64_t shape[4];
+} asrfe_tensor_desc;
+
+/* Fills *cfg with the paraformer-large defaults listed above. */
+int32_t asrfe_default_config(asrfe_config* cfg);
+
+/* Stands in for funasr.AutoModel(model=..., device="cuda:0") (voice_interface.py:686-700):
+ * builds window / mel / twiddle tables on the current device. */
+int32_t asrfe_create(const asrfe_config* cfg, asrfe_ctx** out);
+int32_t asrfe_destroy(asrfe_ctx* ctx);
+
+/* am.mvn of the model directory: y = (x + shift) * scale over lfr_m * n_mels dims (host pointers). */
+int32_t asrfe_load_cmvn(asrfe_ctx* ctx, const float* shift_host, const float* scale_host, int32_t dim);
+
+/* model.pt encoder tensors (host float32); converted to the device layout the kernels use. */
+int32_t asrfe_load_encoder_weights(asrfe_ctx* ctx, const asrfe_tensor_desc* descs, int32_t n);
+
+/* snip_edges frame count and LFR frame count for a clip of n_samples (host helpers). */
+int32_t asrfe_num_frames(const asrfe_ctx* ctx, int64_t n_samples);
+int32_t asrfe_num_lfr_frames(const asrfe_ctx* ctx, int32_t n_frames);
+
+/* kaldi.fbank over a batch: logmel[b, t, :] for t < n_frames[b]; rows t >= n_frames[b] (< t_max) are zero.
+ * logmel: [B, t_max, n_mels] float32, n_frames_out: [B] int32 (device). */
+int32_t asrfe_fbank(asrfe_ctx* ctx, const void* pcm, int32_t pcm_dtype, int64_t pcm_stride,
+                    const int32_t* pcm_lens, int32_t batch, int32_t t_max, float* logmel,
+                    int32_t* n_frames_out, void* stream);
+
+/* apply_lfr + apply_cmvn on [B, t_max, n_mels] log-mel -> feats [B, tp_max, lfr_m * n_mels]
+ * (float32 or bf16 per out_dtype), zero-padded rows past lens_out[b]. */
+int32_t asrfe_lfr_cmvn(asrfe_ctx* ctx, const float* logmel, const int32_t* n_frames, int32_t batch,
+                       int32_t t_max, int32_t tp_max, void* feats, int32_t out_dtype,
+                       int32_t* lens_out, void* stream);
+
+/* WavFrontend.forward fused in one kernel: PCM -> feats [B, tp_max, 560], lens_out [B]. */
+int32_t asrfe_frontend(asrfe_ctx* ctx, const void* pcm, int32_t pcm_dtype, int64_t pcm_stride,
+                       const int32_t* pcm_lens, int32_t batch, int32_t tp_max, void* feats,
+                       int32_t out_dtype, int32_t* lens_out, void* stream);
+
+/* Bytes of device scratch asrfe_encoder_forward needs for a [batch, tp] call. */
+int64_t asrfe_encoder_workspace_bytes(const asrfe_ctx* ctx, int32_t batch, int32_t tp);
+
+/* SANMEncoder.forward: feats [B, tp, 560] float32, lens [B] int32 -> out [B, tp, 512]
+ * (float32 or bf16), rows t >= lens[b] zero.  workspace: >= asrfe_encoder_workspace_bytes, 256-B aligned. */
+int32_t asrfe_encoder_forward(asrfe_ctx* ctx, const float* feats, const int32_t* lens, int32_t batch,
+                              int32_t tp, void* out, int32_t out_dtype, void* workspace,
+                              int64_t workspace_bytes, void* stream);
+
+/* Host-only table builders (double precision, no device needed): the Kaldi mel banks over bins
+ * 0 .. n_fft/2 - 1 as [n_mels][n_fft/2], and the analysis window [frame_length].  These are the
+ * tables asrfe_create uploads; they stand in for torchaudio's get_mel_banks / _feature_window_function
+ * underneath the WavFrontend call sites cited above and let CPU-only tests check them. */
+int32_t asrfe_host_mel_banks(const asrfe_config* cfg, double* out);
+int32_t asrfe_host_window(const asrfe_config* cfg, double* out);
+
+/* Measurement support (no counterpart in the reference).  Between asrfe_profile_begin and
+ * asrfe_profile_end every kernel the encoder / frontend calls enqueue is bracketed by a pair of HIP
+ * events on the call's stream; asrfe_profile_end waits for them and returns, per kernel kind, the
+ * number of launches and the summed launch duration in milliseconds.  Events are created in
+ * asrfe_profile_begin (max_launches pairs), never in the compute calls. */
+#define ASRFE_PROF_KINDS 12
+typedef struct asrfe_profile {
+    int32_t launches[ASRFE_PROF_KINDS];
+    float total_ms[ASRFE_PROF_KINDS];
+} asrfe_profile;
+/* kinds: 0 fbank, 1 frontend(fused), 2 lfr_cmvn, 3 pe_table, 4 layernorm, 5 gemm_qkv, 6 fsmn,
+ *        7 attention, 8 gemm_out, 9 gemm_ffn1, 10 gemm_ffn2, 11 reserved */
+int32_t asrfe_profile_begin(asrfe_ctx* ctx, int32_t max_launches);
+int32_t asrfe_profile_end(asrfe_ctx* ctx, asrfe_profile* out);
+
+/* Text of the last error on this context (or of the last failed asrfe_create when ctx is NULL). */
+const char* asrfe_last_error(const asrfe_ctx* ctx);
+const char* asrfe_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ASRFE_H */

@@ -1,0 +1,149 @@
+"""Generate the committed golden fixtures under tests/golden/.
+
+Run from the repo root:  python tests/golden/make_golden.py
+
+The reference holds no golden vectors for this path and its arithmetic lives in
+packages that are not installed here, so the fixtures are produced by the CPU
+oracle (oracle/fbank_oracle.py, oracle/sanm_oracle.py) and, for fbank, checked
+while generating against an independent Kaldi-fbank implementation that IS
+importable in the build container: ``transformers.audio_utils.spectrogram`` in the
+configuration its own feature extractors use to stand in for
+``torchaudio.compliance.kaldi.fbank`` (pre-emphasis 0.97, DC removal, Kaldi mel
+scale, triangles in mel space, FLT_EPSILON floor, natural log) with a symmetric
+Hamming window.  Only the fixtures travel to the GPU box; transformers is not needed
+there.
+
+Files written:
+  fbank_<kind>_s<seed>_<n>.npz : pcm int16, logmel f32 (T, 80), feats f32 (T', 560), shift/scale f32
+  encoder_tiny.npz             : 2-layer SAN-M encoder, B=2, T'=40 ragged: feats, lens, out (fp64 oracle -> f32)
+  encoder_probe_50l.npz        : 50-layer encoder, B=2, T'=96 ragged: out slices + checksums
+"""
+from __future__ import annotations
+
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+
+from oracle import fbank_oracle as fo  # noqa: E402
+from oracle import sanm_oracle as so  # noqa: E402
+
+OUT = os.path.dirname(os.path.abspath(__file__))
+
+FBANK_CASES = [
+    ("uniform", 0, 16000),
+    ("gauss", 1, 16000),
+    ("chirp", 2, 48000),
+    ("bursts", 3, 48000),
+    ("bench", 4, 16000),
+    ("gauss", 5, 400),  # exactly one frame
+    ("gauss", 6, 1367),  # ragged: 7 frames -> 2 LFR frames with tail replication
+]
+
+
+def cross_check_fbank(pcm: np.ndarray, ours: np.ndarray) -> float:
+    from transformers.audio_utils import mel_filter_bank, spectrogram, window_function
+
+    mel_filters = mel_filter_bank(
+        num_frequency_bins=257,
+        num_mel_filters=80,
+        min_frequency=20,
+        max_frequency=8000,
+        sampling_rate=16000,
+        norm=None,
+        mel_scale="kaldi",
+        triangularize_in_mel_space=True,
+    )
+    window = window_function(400, "hamming", periodic=False)
+    theirs = spectrogram(
+        pcm.astype(np.float64),
+        window,
+        frame_length=400,
+        hop_length=160,
+        fft_length=512,
+        power=2.0,
+        center=False,
+        preemphasis=0.97,
+        mel_filters=mel_filters,
+        log_mel="log",
+        mel_floor=1.192092955078125e-07,
+        remove_dc_offset=True,
+        dtype=np.float64,
+    ).T
+    assert theirs.shape == ours.shape, (theirs.shape, ours.shape)
+    return float(np.max(np.abs(theirs - ours)))
+
+
+def synth_cmvn(seed: int):
+    rng = np.random.default_rng(1000 + seed)
+    shift = -rng.uniform(6.0, 14.0, size=560)
+    scale = 1.0 / rng.uniform(1.5, 4.5, size=560)
+    return shift, scale
+
+
+def main():
+    worst = 0.0
+    for kind, seed, n in FBANK_CASES:
+        pcm = fo.synth_pcm(kind, n, seed)
+        logmel = fo.kaldi_fbank(pcm)
+        err = cross_check_fbank(pcm, logmel)
+        worst = max(worst, err)
+        assert err < 2e-4, f"{kind}/{seed}: oracle vs transformers kaldi-fbank differ by {err}"
+        shift, scale = synth_cmvn(seed)
+        feats = fo.apply_cmvn(fo.apply_lfr(logmel), shift, scale)
+        np.savez_compressed(
+            os.path.join(OUT, f"fbank_{kind}_s{seed}_{n}.npz"),
+            pcm=pcm,
+            logmel=logmel.astype(np.float32),
+            feats=feats.astype(np.float32),
+            shift=shift.astype(np.float32),
+            scale=scale.astype(np.float32),
+        )
+        print(f"fbank {kind:8s} seed {seed} n {n:6d}: T={logmel.shape[0]:4d} T'={feats.shape[0]:3d} "
+              f"max|oracle - transformers| = {err:.3e}")
+    print(f"worst cross-implementation difference: {worst:.3e}")
+
+    # encoder, tiny: full tensors
+    cfg = so.SanmConfig(num_blocks=2)
+    sd = so.make_state_dict(cfg, seed=0, dtype=torch.float64)
+    feats = so.synth_feats(2, 40, 560, seed=11, dtype=torch.float64)
+    lens = torch.tensor([40, 27], dtype=torch.int32)
+    out, olens = so.encoder_forward(feats, lens, sd, cfg)
+    np.savez_compressed(
+        os.path.join(OUT, "encoder_tiny.npz"),
+        feats=feats.numpy().astype(np.float32),
+        lens=lens.numpy(),
+        out=out.numpy().astype(np.float32),
+        olens=olens.numpy(),
+        seed=np.int32(0),
+        num_blocks=np.int32(2),
+    )
+    print("encoder tiny:", tuple(out.shape), "abs max", float(out.abs().max()))
+
+    # encoder, full depth: slices + checksums
+    cfg = so.SanmConfig(num_blocks=50)
+    sd = so.make_state_dict(cfg, seed=0, dtype=torch.float64)
+    feats = so.synth_feats(2, 96, 560, seed=12, dtype=torch.float64)
+    lens = torch.tensor([96, 61], dtype=torch.int32)
+    out, olens = so.encoder_forward(feats, lens, sd, cfg)
+    o = out.numpy()
+    np.savez_compressed(
+        os.path.join(OUT, "encoder_probe_50l.npz"),
+        lens=lens.numpy(),
+        rows_b0=o[0, [0, 1, 47, 95]].astype(np.float32),
+        rows_b1=o[1, [0, 30, 60]].astype(np.float32),
+        col_sums=o.sum(axis=(0, 1)).astype(np.float64),
+        abs_mean=np.float64(np.abs(o).mean()),
+        seed=np.int32(0),
+        feats_seed=np.int32(12),
+        num_blocks=np.int32(50),
+    )
+    print("encoder 50l:", tuple(out.shape), "abs mean", float(np.abs(o).mean()))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,283 @@
+"""GPU parity tests: the HIP path, called through the C ABI (ctypes), against the CPU oracle and the
+committed golden fixtures.  Tolerances follow the stated bars: frame indices / counts exact, log-mel and
+LFR/CMVN features <= 1e-3 absolute (float32 kernels vs float64 oracle), encoder output <= 1e-2 absolute
+(bf16 MFMA GEMMs with fp32 accumulation vs float64/float32 oracle).
+"""
+import glob
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import fbank_oracle as fo
+from oracle import sanm_oracle as so
+
+pytestmark = pytest.mark.gpu
+
+FBANK_TOL = 1e-3
+ENC_TOL = 1e-2
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
+
+
+@pytest.fixture(scope="module")
+def pkg():
+    import toolbox_for_asr_and_tts_amd as p
+
+    p.load()  # raises if the HIP library is missing: there is no fallback to test instead
+    return p
+
+
+@pytest.fixture(scope="module")
+def fe(pkg):
+    return pkg.WavFrontend()
+
+
+def dev(x):
+    return torch.as_tensor(x).to("cuda")
+
+
+def batchify(clips):
+    n = max(len(c) for c in clips)
+    n = (n + 7) // 8 * 8
+    arr = np.zeros((len(clips), max(n, 8)), dtype=clips[0].dtype)
+    for i, c in enumerate(clips):
+        arr[i, : len(c)] = c
+    return arr, [len(c) for c in clips]
+
+
+# ---- fbank -------------------------------------------------------------------------------------
+@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(GOLDEN, "fbank_*.npz"))))
+def test_fbank_golden(fe, path):
+    g = np.load(path)
+    pcm = g["pcm"]
+    out, nfr = fe.forward_fbank(dev(pcm[None]), [len(pcm)])
+    assert int(nfr[0]) == g["logmel"].shape[0] == fo.num_frames(len(pcm))
+    got = out[0].cpu().numpy()
+    assert got.shape == g["logmel"].shape
+    assert np.max(np.abs(got - g["logmel"])) <= FBANK_TOL
+
+
+@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(GOLDEN, "fbank_*.npz"))))
+def test_frontend_golden_fused_and_split(fe, path):
+    g = np.load(path)
+    pcm = g["pcm"]
+    fe.set_cmvn(g["shift"], g["scale"])
+    try:
+        feats, lens = fe.forward(dev(pcm[None]), [len(pcm)])
+        assert int(lens[0]) == g["feats"].shape[0]
+        got = feats[0].cpu().numpy()
+        assert got.shape == g["feats"].shape
+        assert np.max(np.abs(got - g["feats"])) <= FBANK_TOL
+        # split path: fbank kernel then lfr_cmvn kernel must give the same numbers as the fused kernel
+        logmel, nfr = fe.forward_fbank(dev(pcm[None]), [len(pcm)])
+        feats2, lens2 = fe.forward_lfr_cmvn(logmel, nfr.cpu())
+        assert torch.equal(lens2, lens)
+        assert torch.equal(feats2, feats)
+    finally:
+        fe.set_cmvn(np.zeros(560, np.float32), np.ones(560, np.float32))
+
+
+def test_fbank_ragged_batch_and_edges(fe):
+    lens = [0, 1, 399, 400, 401, 559, 560, 1367, 8000, 16001, 3203, 720]
+    kinds = ["gauss", "uniform", "bursts", "chirp"]
+    clips = [fo.synth_pcm(kinds[i % 4], n, 40 + i) if n else np.zeros(0, np.int16) for i, n in enumerate(lens)]
+    arr, ln = batchify(clips)
+    assert ln == lens
+    out, nfr = fe.forward_fbank(dev(arr), ln)
+    want, wn = fo.fbank_batch(arr, ln)
+    assert nfr.cpu().tolist() == wn.tolist() == [fo.num_frames(n) for n in lens]
+    got = out.cpu().numpy()
+    assert got.shape == want.shape
+    assert np.max(np.abs(got - want)) <= FBANK_TOL
+    for b, t in enumerate(wn):
+        assert np.all(got[b, t:] == 0.0), "rows past n_frames must be zero"
+    # fused frontend on the same ragged batch
+    shift = np.linspace(-12, -6, 560).astype(np.float32)
+    scale = np.linspace(0.2, 0.5, 560).astype(np.float32)
+    fe.set_cmvn(shift, scale)
+    try:
+        feats, flens = fe.forward(dev(arr), ln)
+        wf, wl = fo.frontend(arr, ln, shift, scale)
+        assert flens.cpu().tolist() == wl.tolist()
+        gotf = feats.cpu().numpy()
+        assert gotf.shape == wf.shape
+        assert np.max(np.abs(gotf - wf)) <= FBANK_TOL
+        for b, t in enumerate(wl):
+            assert np.all(gotf[b, t:] == 0.0)
+    finally:
+        fe.set_cmvn(np.zeros(560, np.float32), np.ones(560, np.float32))
+
+
+def test_fbank_float_input_equals_int16_input(fe):
+    pcm = fo.synth_pcm("gauss", 16000, 7)
+    a, _ = fe.forward_fbank(dev(pcm[None]), [16000])
+    b, _ = fe.forward_fbank(dev((pcm / 32768.0).astype(np.float32)[None]), [16000])
+    assert torch.equal(a, b)
+
+
+def test_fbank_unaligned_rows_take_the_scalar_path(fe):
+    pcm = fo.synth_pcm("gauss", 4001, 8)
+    big = np.zeros((2, 4003), dtype=np.int16)  # odd row stride -> rows are not 16-byte aligned
+    big[0, :4001] = pcm
+    big[1, :3000] = pcm[:3000]
+    out, nfr = fe.forward_fbank(dev(big), [4001, 3000])
+    want, wn = fo.fbank_batch(big, [4001, 3000])
+    assert nfr.cpu().tolist() == wn.tolist()
+    assert np.max(np.abs(out.cpu().numpy() - want)) <= FBANK_TOL
+
+
+def test_fbank_analytic_known_answers(fe):
+    floor = math.log(fo.LOG_FLOOR)
+    z = np.zeros((1, 16000), np.int16)
+    out, _ = fe.forward_fbank(dev(z), [16000])
+    assert torch.all(out == np.float32(floor))
+    dc = np.full((1, 16000), 1234, np.int16)
+    out, _ = fe.forward_fbank(dev(dc), [16000])
+    assert torch.all(out == np.float32(floor)), "a constant signal must vanish after DC removal"
+    t = np.arange(16000) / 16000.0
+    tone = np.rint(8000 * np.sin(2 * np.pi * 1000.0 * t)).astype(np.int16)[None]
+    out, _ = fe.forward_fbank(dev(tone), [16000])
+    expect = int(np.argmax(fo.mel_banks()[:, 32]))
+    assert torch.all(out[0].argmax(dim=1) == expect)
+
+
+def test_fbank_full_size_properties(fe):
+    """30 s clips (T = 2998, T' = 500): size-independent properties instead of a slow oracle sweep."""
+    n = 480000
+    b = 6
+    arr = np.stack([fo.synth_pcm("bench", n, 1234 + i) for i in range(b)])
+    x = dev(arr)
+    out, nfr = fe.forward_fbank(x, [n] * b)
+    assert out.shape == (b, 2998, 80) and nfr.cpu().tolist() == [2998] * b
+    assert bool(torch.isfinite(out).all())
+    # (1) the zero prefix (first 10 %) sits exactly on the log floor
+    assert torch.all(out[:, : (n // 10 - 400) // 160] == np.float32(math.log(fo.LOG_FLOOR)))
+    # (2) shifting the signal by one hop shifts the frames by one, bit for bit
+    shifted = torch.zeros_like(x)
+    shifted[:, : n - 160] = x[:, 160:]
+    out_s, _ = fe.forward_fbank(shifted, [n - 160] * b)
+    assert torch.equal(out_s[:, :2997], out[:, 1:2998])
+    # (3) results do not depend on the batch position or on the neighbours
+    out_r, _ = fe.forward_fbank(x.flip(0).contiguous(), [n] * b)
+    assert torch.equal(out_r.flip(0), out)
+    # (4) spot rows against the oracle
+    want = fo.kaldi_fbank(arr[2])
+    got = out[2].cpu().numpy()
+    assert np.max(np.abs(got - want)) <= FBANK_TOL
+    # (5) fused LFR/CMVN output is a pure gather of the fbank output (identity CMVN): exact
+    feats, fl = fe.forward(x, [n] * b)
+    assert feats.shape == (b, 500, 560) and fl.cpu().tolist() == [500] * b
+    idx = np.clip(6 * np.arange(500)[:, None] + np.arange(7)[None, :] - 3, 0, 2997)
+    gathered = out[:, torch.as_tensor(idx, device="cuda")].reshape(b, 500, 560)
+    assert torch.equal(feats, gathered)
+
+
+def test_frontend_bf16_output(fe):
+    pcm = fo.synth_pcm("gauss", 16000, 9)
+    f32, _ = fe.forward(dev(pcm[None]), [16000])
+    bf, _ = fe.forward(dev(pcm[None]), [16000], out_dtype=torch.bfloat16)
+    assert torch.equal(bf, f32.to(torch.bfloat16))
+
+
+def test_bad_arguments_raise(pkg, fe):
+    with pytest.raises(ValueError):
+        fe.forward_fbank(torch.zeros(2, 800, dtype=torch.int16), [800, 800])  # host tensor
+    with pytest.raises(ValueError):
+        fe.forward_fbank(dev(np.zeros((2, 800), np.int16)), [800, 801])  # length past the row
+    with pytest.raises(ValueError):
+        fe.forward_fbank(dev(np.zeros((2, 800), np.float64)), [800, 800])
+    enc = pkg.SANMEncoder(num_blocks=1)
+    with pytest.raises(pkg.AsrfeError):  # weights not loaded
+        enc.forward(torch.zeros(1, 8, 560, device="cuda"), [8])
+
+
+# ---- encoder ---------------------------------------------------------------------------------------
+def run_encoder(pkg, num_blocks, seed, feats, lens, out_dtype=torch.float32):
+    cfg = so.SanmConfig(num_blocks=num_blocks)
+    sd = so.make_state_dict(cfg, seed=seed, dtype=torch.float32)
+    enc = pkg.SANMEncoder(num_blocks=num_blocks)
+    enc.load_state_dict(sd)
+    out, olens, _ = enc.forward(feats.to("cuda"), lens, out_dtype=out_dtype)
+    torch.cuda.synchronize()
+    return out, olens, sd, cfg
+
+
+def test_encoder_tiny_golden(pkg):
+    g = np.load(os.path.join(GOLDEN, "encoder_tiny.npz"))
+    feats = torch.from_numpy(g["feats"])
+    out, olens, _, _ = run_encoder(pkg, int(g["num_blocks"]), int(g["seed"]), feats, torch.from_numpy(g["lens"]))
+    assert olens.cpu().tolist() == g["olens"].tolist()
+    got = out.cpu().numpy()
+    err = np.max(np.abs(got - g["out"]))
+    assert err <= ENC_TOL, err
+    assert np.all(got[1, int(g["lens"][1]):] == 0.0)
+
+
+def test_encoder_one_layer_vs_oracle_various_lengths(pkg):
+    """Exercises the key mask, the FSMN edge handling and row tails: T' not a multiple of 64 / 128."""
+    for tp, lens in [(1, [1]), (7, [7, 3]), (65, [65, 64, 1]), (130, [130, 77]), (200, [129, 200, 5, 64])]:
+        feats = so.synth_feats(len(lens), tp, 560, seed=tp)
+        lt = torch.tensor(lens, dtype=torch.int32)
+        out, olens, sd, cfg = run_encoder(pkg, 1, 5, feats, lt)
+        want, wl = so.encoder_forward(feats.double(), lt, {k: v.double() for k, v in sd.items()}, cfg)
+        assert olens.cpu().tolist() == wl.tolist()
+        err = float((out.cpu().double() - want).abs().max())
+        assert err <= ENC_TOL, (tp, lens, err)
+
+
+def test_encoder_50_layers_probe(pkg):
+    g = np.load(os.path.join(GOLDEN, "encoder_probe_50l.npz"))
+    feats = so.synth_feats(2, 96, 560, seed=int(g["feats_seed"]))
+    out, olens, _, _ = run_encoder(pkg, 50, int(g["seed"]), feats, torch.from_numpy(g["lens"]))
+    got = out.cpu().numpy()
+    assert np.isfinite(got).all()
+    e0 = np.max(np.abs(got[0, [0, 1, 47, 95]] - g["rows_b0"]))
+    e1 = np.max(np.abs(got[1, [0, 30, 60]] - g["rows_b1"]))
+    assert max(e0, e1) <= ENC_TOL, (e0, e1)
+    assert np.max(np.abs(got.sum(axis=(0, 1)) - g["col_sums"])) <= ENC_TOL * 157  # 157 valid rows
+    assert abs(np.abs(got).mean() - float(g["abs_mean"])) <= 1e-3
+
+
+def test_encoder_full_length_properties(pkg):
+    """T' = 500 (30 s), 3 layers: padding independence, batch independence, determinism, bf16 output."""
+    tp = 500
+    feats = so.synth_feats(3, tp, 560, seed=21)
+    lens = torch.tensor([500, 333, 64], dtype=torch.int32)
+    out, _, sd, cfg = run_encoder(pkg, 3, 1, feats, lens)
+    want, _ = so.encoder_forward(feats, lens, sd, cfg)
+    assert float((out.cpu() - want).abs().max()) <= ENC_TOL
+    enc = pkg.SANMEncoder(num_blocks=3)
+    enc.load_state_dict(sd)
+    f2 = feats.clone()
+    f2[1, 333:] = 50.0  # garbage in the padding must not reach valid rows
+    out2, _, _ = enc.forward(f2.cuda(), lens)
+    assert torch.equal(out2, out)
+    out3, _, _ = enc.forward(feats.flip(0).contiguous().cuda(), lens.flip(0))
+    assert torch.equal(out3.flip(0), out)
+    outb, _, _ = enc.forward(feats.cuda(), lens, out_dtype=torch.bfloat16)
+    assert torch.equal(outb, out.to(torch.bfloat16))
+    assert float(out[1, 333:].abs().max()) == 0.0 and float(out[2, 64:].abs().max()) == 0.0
+
+
+def test_engine_end_to_end_matches_oracle(pkg):
+    """PCM -> frontend -> 2-layer encoder through AsrEngine (preallocated buffers) vs the oracle chain."""
+    n = 48000  # 3 s: T = 298, T' = 50
+    clips = np.stack([fo.synth_pcm("bursts", n, 70), fo.synth_pcm("gauss", n, 71), fo.synth_pcm("chirp", n, 72)])
+    lens = [48000, 30000, 16000]
+    rng = np.random.default_rng(5)
+    shift = -rng.uniform(6, 14, 560)
+    scale = 1.0 / rng.uniform(1.5, 4.5, 560)
+    cfg_o = so.SanmConfig(num_blocks=2)
+    sd = so.make_state_dict(cfg_o, seed=2)
+    cfg = pkg.default_config()
+    cfg.enc_num_blocks = 2
+    eng = pkg.AsrEngine(batch=3, max_samples=n, cfg=cfg, cmvn=(shift.astype(np.float32), scale.astype(np.float32)),
+                        state_dict=sd)
+    out, olens = eng.run(dev(clips), dev(np.array(lens, np.int32)))
+    torch.cuda.synchronize()
+    wf, wl = fo.frontend(clips, lens, shift, scale)
+    assert olens.cpu().tolist() == wl.tolist()
+    want, _ = so.encoder_forward(torch.from_numpy(wf).float(), torch.from_numpy(wl), sd, cfg_o)
+    assert float((out.cpu() - want).abs().max()) <= ENC_TOL

@@ -1,0 +1,13 @@
+"""MI355X-native speech frontend + Paraformer SAN-M encoder (HIP kernels behind the libasrfe C ABI).
+
+Only the batched hot path lives here: ``WavFrontend`` (Kaldi fbank -> LFR -> CMVN) and ``SANMEncoder``,
+mirroring the FunASR classes the reference service reaches through ``funasr.AutoModel`` / the
+ModelScope pipeline, plus ``AsrEngine`` which runs both back to back on preallocated buffers.
+"""
+from ._lib import AsrfeError, Config, Context, default_config, load  # noqa: F401
+from .frontend import WavFrontend, load_cmvn  # noqa: F401
+from .encoder import SANMEncoder  # noqa: F401
+from .engine import AsrEngine, shard_range  # noqa: F401
+
+__all__ = ["AsrfeError", "Config", "Context", "default_config", "load", "WavFrontend", "load_cmvn",
+           "SANMEncoder", "AsrEngine", "shard_range"]

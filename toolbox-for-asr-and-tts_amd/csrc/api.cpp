@@ -1,0 +1,498 @@
+// libasrfe C ABI: context, device tables, weight loading and argument checking.
+// The compute calls only validate, fill a parameter block and launch; they never allocate.
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <map>
+
+#include "common.h"
+
+using namespace asrfe;
+
+static thread_local std::string g_create_err;
+
+namespace asrfe {
+int32_t set_err(asrfe_ctx* ctx, int32_t code, const std::string& msg) {
+    if (ctx) ctx->err = msg;
+    else g_create_err = msg;
+    return code;
+}
+}  // namespace asrfe
+
+#define HIP_TRY(ctx, expr)                                                                              \
+    do {                                                                                                \
+        hipError_t e__ = (expr);                                                                        \
+        if (e__ != hipSuccess)                                                                          \
+            return set_err(ctx, ASRFE_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e__));     \
+    } while (0)
+
+extern "C" const char* asrfe_version(void) { return "asrfe 0.1.0 (gfx950)"; }
+
+extern "C" const char* asrfe_last_error(const asrfe_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_err.c_str(); }
+
+extern "C" int32_t asrfe_default_config(asrfe_config* c) {
+    if (!c) return ASRFE_ERR_BAD_ARG;
+    c->sample_rate = 16000;
+    c->frame_length = 400;
+    c->frame_shift = 160;
+    c->n_fft = 512;
+    c->n_mels = 80;
+    c->preemph = 0.97f;
+    c->low_freq = 20.0f;
+    c->high_freq = 0.0f;
+    c->window_type = 0;
+    c->lfr_m = 7;
+    c->lfr_n = 6;
+    c->enc_input_size = 560;
+    c->enc_output_size = 512;
+    c->enc_heads = 4;
+    c->enc_linear_units = 2048;
+    c->enc_num_blocks = 50;
+    c->enc_kernel_size = 11;
+    c->enc_sanm_shift = 0;
+    c->enc_ln_eps = 1e-12f;
+    return ASRFE_OK;
+}
+
+// ---- host-side table builders (double precision) -------------------------------------------------
+static double mel_of(double f) { return 1127.0 * std::log(1.0 + f / 700.0); }
+
+// Kaldi mel banks over bins 0..n_fft/2-1; out is [n_mels][n_fft/2] row-major.
+static void build_mel_banks(const asrfe_config& c, std::vector<double>& out) {
+    const int nb = c.n_fft / 2;
+    const double nyq = 0.5 * c.sample_rate;
+    const double hi = c.high_freq > 0.0f ? c.high_freq : nyq + c.high_freq;
+    const double bw = static_cast<double>(c.sample_rate) / c.n_fft;
+    const double mlo = mel_of(c.low_freq), mhi = mel_of(hi);
+    const double delta = (mhi - mlo) / (c.n_mels + 1);
+    out.assign(static_cast<size_t>(c.n_mels) * nb, 0.0);
+    for (int m = 0; m < c.n_mels; ++m) {
+        const double left = mlo + m * delta, center = mlo + (m + 1.0) * delta, right = mlo + (m + 2.0) * delta;
+        for (int k = 0; k < nb; ++k) {
+            const double mel = mel_of(bw * k);
+            const double up = (mel - left) / (center - left);
+            const double down = (right - mel) / (right - center);
+            const double w = std::fmax(0.0, std::fmin(up, down));
+            out[static_cast<size_t>(m) * nb + k] = w;
+        }
+    }
+}
+
+static void build_window(const asrfe_config& c, std::vector<double>& w) {
+    const int n = c.frame_length;
+    w.assign(n, 1.0);
+    const double a = 2.0 * M_PI / (n - 1);
+    for (int i = 0; i < n; ++i) {
+        switch (c.window_type) {
+            case 0: w[i] = 0.54 - 0.46 * std::cos(a * i); break;
+            case 1: w[i] = 0.5 - 0.5 * std::cos(a * i); break;
+            case 2: w[i] = std::pow(0.5 - 0.5 * std::cos(a * i), 0.85); break;
+            default: w[i] = 1.0; break;
+        }
+    }
+}
+
+// Host-only helpers exported for the CPU tests (no device needed).
+extern "C" int32_t asrfe_host_mel_banks(const asrfe_config* cfg, double* out /* [n_mels][n_fft/2] */) {
+    if (!cfg || !out || cfg->n_mels <= 0 || cfg->n_fft <= 0) return ASRFE_ERR_BAD_ARG;
+    std::vector<double> v;
+    build_mel_banks(*cfg, v);
+    std::memcpy(out, v.data(), v.size() * sizeof(double));
+    return ASRFE_OK;
+}
+extern "C" int32_t asrfe_host_window(const asrfe_config* cfg, double* out /* [frame_length] */) {
+    if (!cfg || !out || cfg->frame_length <= 1) return ASRFE_ERR_BAD_ARG;
+    std::vector<double> v;
+    build_window(*cfg, v);
+    std::memcpy(out, v.data(), v.size() * sizeof(double));
+    return ASRFE_OK;
+}
+
+template <typename T>
+static int32_t upload(asrfe_ctx* ctx, const std::vector<T>& host, T** dev) {
+    void* p = nullptr;
+    HIP_TRY(ctx, hipMalloc(&p, std::max<size_t>(host.size() * sizeof(T), 16)));
+    ctx->owned.push_back(p);
+    HIP_TRY(ctx, hipMemcpy(p, host.data(), host.size() * sizeof(T), hipMemcpyHostToDevice));
+    *dev = static_cast<T*>(p);
+    return ASRFE_OK;
+}
+
+static uint16_t bf16_rne(float f) {
+    uint32_t u;
+    std::memcpy(&u, &f, 4);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return static_cast<uint16_t>((u >> 16) | 0x40);  // NaN stays NaN
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return static_cast<uint16_t>(u >> 16);
+}
+
+static int32_t check_config(const asrfe_config& c, std::string& why) {
+    if (c.frame_length != kFrameLen || c.frame_shift != kFrameShift || c.n_fft != kNfft) {
+        why = "only frame_length 400 / frame_shift 160 / n_fft 512 kernels are built";
+        return ASRFE_ERR_BAD_ARG;
+    }
+    if (c.n_mels < 1 || c.n_mels > kMaxMels) { why = "n_mels must be in 1..80"; return ASRFE_ERR_BAD_ARG; }
+    if (c.lfr_m < 1 || c.lfr_n < 1 || c.lfr_m > 16) { why = "bad lfr_m / lfr_n"; return ASRFE_ERR_BAD_ARG; }
+    if (c.preemph != 0.97f) { why = "only pre-emphasis 0.97 is built"; return ASRFE_ERR_BAD_ARG; }
+    if (c.enc_output_size != 512 || c.enc_heads != 4) {
+        why = "only enc_output_size 512 with 4 heads (d_k 128) kernels are built";
+        return ASRFE_ERR_BAD_ARG;
+    }
+    if (c.enc_linear_units % 256 != 0 || c.enc_linear_units <= 0) { why = "enc_linear_units must be a multiple of 256"; return ASRFE_ERR_BAD_ARG; }
+    if (c.enc_kernel_size != 11 || c.enc_sanm_shift != 0) { why = "only FSMN kernel 11 / shift 0 is built"; return ASRFE_ERR_BAD_ARG; }
+    if (c.enc_input_size < 8 || c.enc_input_size > 640 || c.enc_input_size % 8 != 0) { why = "enc_input_size must be a multiple of 8 in 8..640"; return ASRFE_ERR_BAD_ARG; }
+    if (c.enc_num_blocks < 1) { why = "enc_num_blocks must be >= 1"; return ASRFE_ERR_BAD_ARG; }
+    return ASRFE_OK;
+}
+
+extern "C" int32_t asrfe_create(const asrfe_config* cfg, asrfe_ctx** out) {
+    if (!cfg || !out) return set_err(nullptr, ASRFE_ERR_BAD_ARG, "asrfe_create: null argument");
+    *out = nullptr;
+    std::string why;
+    if (check_config(*cfg, why) != ASRFE_OK) return set_err(nullptr, ASRFE_ERR_BAD_ARG, "asrfe_create: " + why);
+    int dev = 0;
+    HIP_TRY(nullptr, hipGetDevice(&dev));
+    hipDeviceProp_t prop;
+    HIP_TRY(nullptr, hipGetDeviceProperties(&prop, dev));
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return set_err(nullptr, ASRFE_ERR_UNSUPPORTED_ARCH, std::string("asrfe_create: built for gfx950, device is ") + prop.gcnArchName);
+
+    asrfe_ctx* ctx = new asrfe_ctx();
+    ctx->cfg = *cfg;
+    ctx->device = dev;
+    ctx->cmvn_loaded = false;
+    ctx->enc_loaded = false;
+    ctx->kin_pad = (cfg->enc_input_size + 63) / 64 * 64;
+    ctx->after_g = ctx->after_b = ctx->pe_inv = nullptr;
+    std::memset(&ctx->tab, 0, sizeof(ctx->tab));
+
+    auto fail = [&](int32_t rc) {
+        g_create_err = ctx->err;
+        asrfe_destroy(ctx);
+        return rc;
+    };
+
+    // window, zero-padded
+    std::vector<double> wd;
+    build_window(*cfg, wd);
+    std::vector<float> wf(kWinPad, 0.0f);
+    for (int i = 0; i < kFrameLen; ++i) wf[i] = static_cast<float>(wd[i]);
+    int32_t rc = upload(ctx, wf, &ctx->tab.window);
+    if (rc) return fail(rc);
+
+    // twiddles
+    std::vector<float2> t256(256), t512(129);
+    for (int n2 = 0; n2 < 16; ++n2)
+        for (int k1 = 0; k1 < 16; ++k1) {
+            const double a = 2.0 * M_PI * n2 * k1 / 256.0;
+            t256[n2 * 16 + k1] = make_float2(static_cast<float>(std::cos(a)), static_cast<float>(-std::sin(a)));
+        }
+    for (int k = 0; k <= 128; ++k) {
+        const double a = 2.0 * M_PI * k / 512.0;
+        t512[k] = make_float2(static_cast<float>(std::cos(a)), static_cast<float>(-std::sin(a)));
+    }
+    if ((rc = upload(ctx, t256, &ctx->tab.tw256))) return fail(rc);
+    if ((rc = upload(ctx, t512, &ctx->tab.tw512))) return fail(rc);
+
+    // mel filters: per-lane CSR, zero-padded to the widest filter of each group of 16
+    std::vector<double> banks;
+    build_mel_banks(*cfg, banks);
+    const int nb = kNc;
+    std::vector<int> start(kMelGroups * 16, 1), width(kMelGroups * 16, 0);
+    for (int m = 0; m < cfg->n_mels; ++m) {
+        int lo = -1, hi = -1;
+        for (int k = 0; k < nb; ++k)
+            if (banks[static_cast<size_t>(m) * nb + k] != 0.0) {
+                if (lo < 0) lo = k;
+                hi = k;
+            }
+        if (lo == 0) lo = 1;  // bin 0 is never produced by the kernel (its Kaldi weight is 0 for low_freq > 0)
+        if (lo >= 1 && hi >= lo) {
+            start[(m / 16) * 16 + (m % 16)] = lo;
+            width[(m / 16) * 16 + (m % 16)] = hi - lo + 1;
+        }
+    }
+    if (cfg->low_freq <= 0.0f) {
+        ctx->err = "asrfe_create: low_freq must be > 0 (the DC bin is not computed)";
+        return fail(ASRFE_ERR_BAD_ARG);
+    }
+    int total = 0;
+    for (int g = 0; g < kMelGroups; ++g) {
+        int gw = 0;
+        for (int l = 0; l < 16; ++l) gw = std::max(gw, width[g * 16 + l]);
+        ctx->tab.mel_gw[g] = gw;
+        ctx->tab.mel_go[g] = total;
+        total += gw;
+    }
+    if (total > kMelMaxTerms) {
+        ctx->err = "asrfe_create: mel filters too wide for the kernel's table";
+        return fail(ASRFE_ERR_BAD_ARG);
+    }
+    std::vector<float> mw(kMelMaxTerms * 16, 0.0f);
+    std::vector<int32_t> msb(kMelGroups * 16, 1);
+    for (int g = 0; g < kMelGroups; ++g)
+        for (int l = 0; l < 16; ++l) {
+            const int m = g * 16 + l;
+            msb[g * 16 + l] = start[g * 16 + l];
+            if (m >= cfg->n_mels) continue;
+            for (int j = 0; j < width[g * 16 + l]; ++j)
+                mw[(ctx->tab.mel_go[g] + j) * 16 + l] =
+                    static_cast<float>(0.25 * banks[static_cast<size_t>(m) * nb + start[g * 16 + l] + j]);
+        }
+    if ((rc = upload(ctx, mw, &ctx->tab.mel_w))) return fail(rc);
+    if ((rc = upload(ctx, msb, &ctx->tab.mel_sb))) return fail(rc);
+
+    // identity CMVN until asrfe_load_cmvn is called
+    const int dim = cfg->lfr_m * cfg->n_mels;
+    std::vector<float> z(dim, 0.0f), o(dim, 1.0f);
+    if ((rc = upload(ctx, z, &ctx->tab.cmvn_shift))) return fail(rc);
+    if ((rc = upload(ctx, o, &ctx->tab.cmvn_scale))) return fail(rc);
+
+    // inverse timescales of the sinusoidal position code over enc_input_size dims
+    const int half = cfg->enc_input_size / 2;
+    std::vector<float> inv(half);
+    const double inc = std::log(10000.0) / (half - 1);
+    for (int i = 0; i < half; ++i) inv[i] = static_cast<float>(std::exp(-inc * i));
+    if ((rc = upload(ctx, inv, &ctx->pe_inv))) return fail(rc);
+
+    *out = ctx;
+    return ASRFE_OK;
+}
+
+extern "C" int32_t asrfe_profile_begin(asrfe_ctx* ctx, int32_t max_launches) {
+    if (!ctx || max_launches < 1 || max_launches > (1 << 20)) return set_err(ctx, ASRFE_ERR_BAD_ARG, "asrfe_profile_begin: bad argument");
+    while (ctx->prof_events.size() < static_cast<size_t>(max_launches) * 2) {
+        hipEvent_t e;
+        HIP_TRY(ctx, hipEventCreate(&e));
+        ctx->prof_events.push_back(e);
+    }
+    ctx->prof_kind.assign(ctx->prof_events.size() / 2, 0);
+    ctx->prof_used = 0;
+    ctx->prof_on = true;
+    return ASRFE_OK;
+}
+
+extern "C" int32_t asrfe_profile_end(asrfe_ctx* ctx, asrfe_profile* out) {
+    if (!ctx || !out) return set_err(ctx, ASRFE_ERR_BAD_ARG, "asrfe_profile_end: null argument");
+    ctx->prof_on = false;
+    std::memset(out, 0, sizeof(*out));
+    for (size_t i = 0; i < ctx->prof_used; ++i) {
+        HIP_TRY(ctx, hipEventSynchronize(ctx->prof_events[2 * i + 1]));
+        float ms = 0.0f;
+        HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->prof_events[2 * i], ctx->prof_events[2 * i + 1]));
+        const int k = ctx->prof_kind[i];
+        if (k >= 0 && k < ASRFE_PROF_KINDS) {
+            out->launches[k] += 1;
+            out->total_ms[k] += ms;
+        }
+    }
+    ctx->prof_used = 0;
+    return ASRFE_OK;
+}
+
+extern "C" int32_t asrfe_destroy(asrfe_ctx* ctx) {
+    if (!ctx) return ASRFE_OK;
+    for (hipEvent_t e : ctx->prof_events) (void)hipEventDestroy(e);
+    for (void* p : ctx->owned) (void)hipFree(p);
+    delete ctx;
+    return ASRFE_OK;
+}
+
+extern "C" int32_t asrfe_load_cmvn(asrfe_ctx* ctx, const float* shift, const float* scale, int32_t dim) {
+    if (!ctx || !shift || !scale) return set_err(ctx, ASRFE_ERR_BAD_ARG, "asrfe_load_cmvn: null argument");
+    if (dim != ctx->cfg.lfr_m * ctx->cfg.n_mels)
+        return set_err(ctx, ASRFE_ERR_SHAPE, "asrfe_load_cmvn: dim must be lfr_m * n_mels");
+    HIP_TRY(ctx, hipMemcpy(ctx->tab.cmvn_shift, shift, dim * sizeof(float), hipMemcpyHostToDevice));
+    HIP_TRY(ctx, hipMemcpy(ctx->tab.cmvn_scale, scale, dim * sizeof(float), hipMemcpyHostToDevice));
+    ctx->cmvn_loaded = true;
+    return ASRFE_OK;
+}
+
+// ---- encoder weights ---------------------------------------------------------------------------
+struct HostTensor {
+    const float* data;
+    std::vector<int64_t> shape;
+    int64_t numel() const {
+        int64_t n = 1;
+        for (auto s : shape) n *= s;
+        return n;
+    }
+};
+
+static int32_t need(asrfe_ctx* ctx, const std::map<std::string, HostTensor>& m, const std::string& name,
+                    std::vector<int64_t> shape, const HostTensor** out) {
+    auto it = m.find(name);
+    if (it == m.end()) return set_err(ctx, ASRFE_ERR_NOT_LOADED, "asrfe_load_encoder_weights: missing tensor " + name);
+    if (it->second.shape != shape) return set_err(ctx, ASRFE_ERR_SHAPE, "asrfe_load_encoder_weights: bad shape for " + name);
+    *out = &it->second;
+    return ASRFE_OK;
+}
+
+static int32_t up_f32(asrfe_ctx* ctx, const HostTensor* t, float** dev) {
+    std::vector<float> v(t->data, t->data + t->numel());
+    return upload(ctx, v, dev);
+}
+
+// [n][k] float -> bf16 [n][k_pad] with zero columns past k
+static int32_t up_bf16(asrfe_ctx* ctx, const HostTensor* t, int k_pad, uint16_t** dev) {
+    const int64_t n = t->shape[0], k = t->shape[1];
+    std::vector<uint16_t> v(static_cast<size_t>(n) * k_pad, 0);
+    for (int64_t r = 0; r < n; ++r)
+        for (int64_t c = 0; c < k; ++c) v[r * k_pad + c] = bf16_rne(t->data[r * k + c]);
+    return upload(ctx, v, dev);
+}
+
+extern "C" int32_t asrfe_load_encoder_weights(asrfe_ctx* ctx, const asrfe_tensor_desc* descs, int32_t n) {
+    if (!ctx || !descs || n <= 0) return set_err(ctx, ASRFE_ERR_BAD_ARG, "asrfe_load_encoder_weights: null argument");
+    if (ctx->enc_loaded) return set_err(ctx, ASRFE_ERR_BAD_ARG, "asrfe_load_encoder_weights: weights already loaded");
+    std::map<std::string, HostTensor> m;
+    for (int i = 0; i < n; ++i) {
+        if (!descs[i].name || !descs[i].data_host || descs[i].ndim < 1 || descs[i].ndim > 4)
+            return set_err(ctx, ASRFE_ERR_BAD_ARG, "asrfe_load_encoder_weights: bad descriptor");
+        HostTensor t;
+        t.data = descs[i].data_host;
+        t.shape.assign(descs[i].shape, descs[i].shape + descs[i].ndim);
+        std::string name = descs[i].name;
+        if (name.rfind("encoder.", 0) == 0) name = name.substr(8);
+        m[name] = t;
+    }
+    const asrfe_config& c = ctx->cfg;
+    const int64_t d = c.enc_output_size, ff = c.enc_linear_units, ks = c.enc_kernel_size;
+    ctx->layers.assign(c.enc_num_blocks, LayerWeights{});
+    int32_t rc;
+    for (int li = 0; li < c.enc_num_blocks; ++li) {
+        const std::string p = li == 0 ? std::string("encoders0.0") : "encoders." + std::to_string(li - 1);
+        const int64_t din = li == 0 ? c.enc_input_size : d;
+        const int kpad = li == 0 ? ctx->kin_pad : static_cast<int>(d);
+        LayerWeights& L = ctx->layers[li];
+        const HostTensor* t;
+        if ((rc = need(ctx, m, p + ".norm1.weight", {din}, &t)) || (rc = up_f32(ctx, t, &L.ln1_g))) return rc;
+        if ((rc = need(ctx, m, p + ".norm1.bias", {din}, &t)) || (rc = up_f32(ctx, t, &L.ln1_b))) return rc;
+        if ((rc = need(ctx, m, p + ".self_attn.linear_q_k_v.weight", {3 * d, din}, &t)) || (rc = up_bf16(ctx, t, kpad, &L.w_qkv))) return rc;
+        if ((rc = need(ctx, m, p + ".self_attn.linear_q_k_v.bias", {3 * d}, &t)) || (rc = up_f32(ctx, t, &L.b_qkv))) return rc;
+        if ((rc = need(ctx, m, p + ".self_attn.fsmn_block.weight", {d, 1, ks}, &t))) return rc;
+        {
+            std::vector<float> w(static_cast<size_t>(ks) * d);
+            for (int64_t ch = 0; ch < d; ++ch)
+                for (int64_t j = 0; j < ks; ++j) w[j * d + ch] = t->data[ch * ks + j];
+            if ((rc = upload(ctx, w, &L.w_fsmn))) return rc;
+        }
+        if ((rc = need(ctx, m, p + ".self_attn.linear_out.weight", {d, d}, &t)) || (rc = up_bf16(ctx, t, static_cast<int>(d), &L.w_out))) return rc;
+        if ((rc = need(ctx, m, p + ".self_attn.linear_out.bias", {d}, &t)) || (rc = up_f32(ctx, t, &L.b_out))) return rc;
+        if ((rc = need(ctx, m, p + ".norm2.weight", {d}, &t)) || (rc = up_f32(ctx, t, &L.ln2_g))) return rc;
+        if ((rc = need(ctx, m, p + ".norm2.bias", {d}, &t)) || (rc = up_f32(ctx, t, &L.ln2_b))) return rc;
+        if ((rc = need(ctx, m, p + ".feed_forward.w_1.weight", {ff, d}, &t)) || (rc = up_bf16(ctx, t, static_cast<int>(d), &L.w_ffn1))) return rc;
+        if ((rc = need(ctx, m, p + ".feed_forward.w_1.bias", {ff}, &t)) || (rc = up_f32(ctx, t, &L.b_ffn1))) return rc;
+        if ((rc = need(ctx, m, p + ".feed_forward.w_2.weight", {d, ff}, &t)) || (rc = up_bf16(ctx, t, static_cast<int>(ff), &L.w_ffn2))) return rc;
+        if ((rc = need(ctx, m, p + ".feed_forward.w_2.bias", {d}, &t)) || (rc = up_f32(ctx, t, &L.b_ffn2))) return rc;
+    }
+    const HostTensor* t;
+    if ((rc = need(ctx, m, "after_norm.weight", {d}, &t)) || (rc = up_f32(ctx, t, &ctx->after_g))) return rc;
+    if ((rc = need(ctx, m, "after_norm.bias", {d}, &t)) || (rc = up_f32(ctx, t, &ctx->after_b))) return rc;
+    HIP_TRY(ctx, hipDeviceSynchronize());
+    ctx->enc_loaded = true;
+    return ASRFE_OK;
+}
+
+// ---- frontend entry points ---------------------------------------------------------------------
+extern "C" int32_t asrfe_num_frames(const asrfe_ctx* ctx, int64_t n) {
+    const int fl = ctx ? ctx->cfg.frame_length : kFrameLen, fs = ctx ? ctx->cfg.frame_shift : kFrameShift;
+    return n < fl ? 0 : static_cast<int32_t>(1 + (n - fl) / fs);
+}
+extern "C" int32_t asrfe_num_lfr_frames(const asrfe_ctx* ctx, int32_t t) {
+    const int n = ctx ? ctx->cfg.lfr_n : 6;
+    return t <= 0 ? 0 : (t + n - 1) / n;
+}
+
+static int32_t fill_common(asrfe_ctx* ctx, FbankParams& p, const void* pcm, int32_t pcm_dtype, int64_t stride,
+                           const int32_t* lens, int32_t batch, const char* who) {
+    if (!ctx) return ASRFE_ERR_BAD_ARG;
+    if (batch < 0 || batch > 65535) return set_err(ctx, ASRFE_ERR_SHAPE, std::string(who) + ": batch must be in 0..65535");
+    if (batch == 0) return ASRFE_OK;
+    if (!pcm || !lens) return set_err(ctx, ASRFE_ERR_BAD_ARG, std::string(who) + ": null pcm / lens");
+    if (pcm_dtype != ASRFE_PCM_I16 && pcm_dtype != ASRFE_PCM_F32) return set_err(ctx, ASRFE_ERR_BAD_ARG, std::string(who) + ": bad pcm_dtype");
+    if (stride < 0) return set_err(ctx, ASRFE_ERR_SHAPE, std::string(who) + ": negative pcm_stride");
+    const int64_t es = pcm_dtype == ASRFE_PCM_I16 ? 2 : 4;
+    p.pcm = pcm;
+    p.pcm_stride = stride;
+    p.pcm_lens = lens;
+    p.batch = batch;
+    p.n_mels = ctx->cfg.n_mels;
+    p.lfr_m = ctx->cfg.lfr_m;
+    p.lfr_n = ctx->cfg.lfr_n;
+    p.aligned16 = (reinterpret_cast<uintptr_t>(pcm) % 16 == 0 && (stride * es) % 16 == 0) ? 1 : 0;
+    p.tab = ctx->tab;
+    return ASRFE_OK;
+}
+
+extern "C" int32_t asrfe_fbank(asrfe_ctx* ctx, const void* pcm, int32_t pcm_dtype, int64_t pcm_stride,
+                               const int32_t* pcm_lens, int32_t batch, int32_t t_max, float* logmel,
+                               int32_t* n_frames_out, void* stream) {
+    FbankParams p{};
+    int32_t rc = fill_common(ctx, p, pcm, pcm_dtype, pcm_stride, pcm_lens, batch, "asrfe_fbank");
+    if (rc || batch == 0) return rc;
+    if (t_max < 1 || t_max > (1 << 26)) return set_err(ctx, ASRFE_ERR_SHAPE, "asrfe_fbank: t_max must be >= 1");
+    if (!logmel) return set_err(ctx, ASRFE_ERR_BAD_ARG, "asrfe_fbank: null logmel");
+    p.t_max = t_max;
+    p.logmel = logmel;
+    p.n_frames = n_frames_out;
+    ProfScope ps(ctx, PK_FBANK, static_cast<hipStream_t>(stream));
+    return launch_fbank(ctx, p, pcm_dtype, false, ASRFE_DT_F32, static_cast<hipStream_t>(stream));
+}
+
+extern "C" int32_t asrfe_lfr_cmvn(asrfe_ctx* ctx, const float* logmel, const int32_t* n_frames, int32_t batch,
+                                  int32_t t_max, int32_t tp_max, void* feats, int32_t out_dtype, int32_t* lens_out,
+                                  void* stream) {
+    if (!ctx) return ASRFE_ERR_BAD_ARG;
+    if (batch < 0 || batch > 65535 || t_max < 1 || tp_max < 1 || tp_max > 65535)
+        return set_err(ctx, ASRFE_ERR_SHAPE, "asrfe_lfr_cmvn: batch in 0..65535, t_max >= 1, tp_max in 1..65535");
+    if (batch == 0) return ASRFE_OK;
+    if (!logmel || !n_frames || !feats) return set_err(ctx, ASRFE_ERR_BAD_ARG, "asrfe_lfr_cmvn: null argument");
+    if (out_dtype != ASRFE_DT_F32 && out_dtype != ASRFE_DT_BF16) return set_err(ctx, ASRFE_ERR_BAD_ARG, "asrfe_lfr_cmvn: bad out_dtype");
+    ProfScope ps(ctx, PK_LFR_CMVN, static_cast<hipStream_t>(stream));
+    return launch_lfr_cmvn(ctx, logmel, n_frames, batch, t_max, tp_max, feats, out_dtype, lens_out,
+                           static_cast<hipStream_t>(stream));
+}
+
+extern "C" int32_t asrfe_frontend(asrfe_ctx* ctx, const void* pcm, int32_t pcm_dtype, int64_t pcm_stride,
+                                  const int32_t* pcm_lens, int32_t batch, int32_t tp_max, void* feats,
+                                  int32_t out_dtype, int32_t* lens_out, void* stream) {
+    FbankParams p{};
+    int32_t rc = fill_common(ctx, p, pcm, pcm_dtype, pcm_stride, pcm_lens, batch, "asrfe_frontend");
+    if (rc || batch == 0) return rc;
+    if (tp_max < 1 || tp_max > (1 << 24)) return set_err(ctx, ASRFE_ERR_SHAPE, "asrfe_frontend: tp_max must be >= 1");
+    if (!feats) return set_err(ctx, ASRFE_ERR_BAD_ARG, "asrfe_frontend: null feats");
+    if (out_dtype != ASRFE_DT_F32 && out_dtype != ASRFE_DT_BF16) return set_err(ctx, ASRFE_ERR_BAD_ARG, "asrfe_frontend: bad out_dtype");
+    p.t_max = tp_max * ctx->cfg.lfr_n;
+    p.tp_max = tp_max;
+    p.feats = feats;
+    p.lfr_lens = lens_out;
+    ProfScope ps(ctx, PK_FRONTEND, static_cast<hipStream_t>(stream));
+    return launch_fbank(ctx, p, pcm_dtype, true, out_dtype, static_cast<hipStream_t>(stream));
+}
+
+// ---- encoder entry points ----------------------------------------------------------------------
+extern "C" int64_t asrfe_encoder_workspace_bytes(const asrfe_ctx* ctx, int32_t batch, int32_t tp) {
+    if (!ctx || batch < 0 || tp < 0) return -1;
+    return encoder_workspace_bytes(ctx, batch, tp);
+}
+
+extern "C" int32_t asrfe_encoder_forward(asrfe_ctx* ctx, const float* feats, const int32_t* lens, int32_t batch,
+                                         int32_t tp, void* out, int32_t out_dtype, void* workspace,
+                                         int64_t workspace_bytes, void* stream) {
+    if (!ctx) return ASRFE_ERR_BAD_ARG;
+    if (!ctx->enc_loaded) return set_err(ctx, ASRFE_ERR_NOT_LOADED, "asrfe_encoder_forward: encoder weights not loaded");
+    if (batch < 0 || batch > 16384 || tp < 0 || tp > 8192)
+        return set_err(ctx, ASRFE_ERR_SHAPE, "asrfe_encoder_forward: batch in 0..16384, tp in 0..8192");
+    if (batch == 0 || tp == 0) return ASRFE_OK;
+    if (static_cast<int64_t>(batch) * tp > (1 << 24)) return set_err(ctx, ASRFE_ERR_SHAPE, "asrfe_encoder_forward: batch * tp too large");
+    if (!feats || !lens || !out || !workspace) return set_err(ctx, ASRFE_ERR_BAD_ARG, "asrfe_encoder_forward: null argument");
+    if (out_dtype != ASRFE_DT_F32 && out_dtype != ASRFE_DT_BF16) return set_err(ctx, ASRFE_ERR_BAD_ARG, "asrfe_encoder_forward: bad out_dtype");
+    if (reinterpret_cast<uintptr_t>(workspace) % 256 != 0) return set_err(ctx, ASRFE_ERR_WORKSPACE, "asrfe_encoder_forward: workspace must be 256-byte aligned");
+    if (reinterpret_cast<uintptr_t>(feats) % 16 != 0 || reinterpret_cast<uintptr_t>(out) % 16 != 0)
+        return set_err(ctx, ASRFE_ERR_BAD_ARG, "asrfe_encoder_forward: feats / out must be 16-byte aligned");
+    if (workspace_bytes < encoder_workspace_bytes(ctx, batch, tp))
+        return set_err(ctx, ASRFE_ERR_WORKSPACE, "asrfe_encoder_forward: workspace too small");
+    return encoder_forward(ctx, feats, lens, batch, tp, out, out_dtype, workspace, workspace_bytes,
+                           static_cast<hipStream_t>(stream));
+}

@@ -1,0 +1,140 @@
+// SAN-M encoder forward: carves the caller's workspace and enqueues the per-layer kernels.
+//
+// Per layer (d = 512):   h = LN1(x)                      ln kernel            bf16 [M][K]
+//                         qkv = h Wqkv^T + b              MFMA GEMM            bf16 [M][1536]
+//                         fsmn, V^T = FSMN(v), mask       fsmn kernel          f32 [M][512], bf16 [B][512][Tk]
+//                         att = softmax(q k^T / sqrt(128)) v   attention kernel bf16 [M][512]
+//                         x = att Wo^T + b + fsmn (+ x)   MFMA GEMM            f32 [M][512]   (layer 0 has no residual)
+//                         h = LN2(x)                      ln kernel
+//                         f = relu(h W1^T + b)            MFMA GEMM            bf16 [M][2048]
+//                         x = f W2^T + b + x              MFMA GEMM            f32 [M][512]
+// The residual stream x stays fp32; GEMM inputs are bf16 with fp32 accumulation.
+#include <cmath>
+
+#include "common.h"
+#include "encoder.h"
+#include "gemm.h"
+
+namespace asrfe {
+
+namespace {
+struct Carve {
+    char* base;
+    int64_t off = 0;
+    template <typename T>
+    T* take(int64_t n) {
+        T* p = reinterpret_cast<T*>(base + off);
+        off += (n * static_cast<int64_t>(sizeof(T)) + 255) / 256 * 256;
+        return p;
+    }
+};
+
+struct Buffers {
+    float* x;        // [M][512]
+    uint16_t* h;     // [M][max(kin_pad, 512)]
+    uint16_t* qkv;   // [M][1536]
+    uint16_t* vt;    // [B][512][Tk]
+    float* fsmn;     // [M][512]
+    uint16_t* att;   // [M][512]
+    uint16_t* ffn;   // [M][ff]
+    float* pe;       // [Tp][din]
+    int64_t bytes;
+};
+
+Buffers carve(const asrfe_ctx* ctx, void* ws, int B, int Tp) {
+    const int64_t M = static_cast<int64_t>(B) * Tp;
+    const int64_t Tk = (Tp + 63) / 64 * 64;
+    const int64_t hk = ctx->kin_pad > 512 ? ctx->kin_pad : 512;
+    Carve c{static_cast<char*>(ws)};
+    Buffers b;
+    b.x = c.take<float>(M * 512);
+    b.h = c.take<uint16_t>(M * hk);
+    b.qkv = c.take<uint16_t>(M * 1536);
+    b.vt = c.take<uint16_t>(static_cast<int64_t>(B) * 512 * Tk);
+    b.fsmn = c.take<float>(M * 512);
+    b.att = c.take<uint16_t>(M * 512);
+    b.ffn = c.take<uint16_t>(M * ctx->cfg.enc_linear_units);
+    b.pe = c.take<float>(static_cast<int64_t>(Tp) * ctx->cfg.enc_input_size);
+    b.bytes = c.off;
+    return b;
+}
+}  // namespace
+
+int64_t encoder_workspace_bytes(const asrfe_ctx* ctx, int batch, int tp) {
+    return carve(ctx, nullptr, batch, tp).bytes;
+}
+
+int32_t encoder_forward(asrfe_ctx* ctx, const float* feats, const int32_t* lens, int B, int Tp, void* out, int out_dtype,
+                        void* ws, int64_t ws_bytes, hipStream_t s) {
+    (void)ws_bytes;
+    const asrfe_config& c = ctx->cfg;
+    const int M = B * Tp;
+    const int Tk = (Tp + 63) / 64 * 64;
+    const int ff = c.enc_linear_units;
+    const Buffers bf = carve(ctx, ws, B, Tp);
+    int32_t rc;
+
+    {
+        ProfScope ps(ctx, PK_PE, s);
+        if ((rc = launch_pe_table(ctx, ctx->pe_inv, Tp, c.enc_input_size, bf.pe, s))) return rc;
+    }
+
+    for (int li = 0; li < c.enc_num_blocks; ++li) {
+        const LayerWeights& L = ctx->layers[li];
+        const int kin = li == 0 ? ctx->kin_pad : 512;
+        {
+        ProfScope ps(ctx, PK_LN, s);
+        if (li == 0) {
+            rc = launch_ln_input(ctx, feats, bf.pe, std::sqrt(static_cast<float>(c.enc_output_size)), L.ln1_g, L.ln1_b,
+                                 c.enc_ln_eps, M, Tp, c.enc_input_size, bf.h, kin, s);
+        } else {
+            rc = launch_ln512(ctx, bf.x, L.ln1_g, L.ln1_b, c.enc_ln_eps, M, bf.h, s);
+        }
+        }
+        if (rc) return rc;
+
+        GemmParams g{};
+        g.A = bf.h; g.lda = kin; g.W = L.w_qkv; g.ldw = kin; g.bias = L.b_qkv;
+        g.M = M; g.N = 1536; g.K = kin; g.out = bf.qkv; g.ldo = 1536;
+        { ProfScope ps(ctx, PK_GEMM_QKV, s); rc = launch_gemm(ctx, g, EPI_BF16, s); }
+        if (rc) return rc;
+
+        { ProfScope ps(ctx, PK_FSMN, s); rc = launch_fsmn(ctx, bf.qkv, 1536, L.w_fsmn, lens, B, Tp, Tk, bf.fsmn, bf.vt, s); }
+        if (rc) return rc;
+
+        AttnParams a{};
+        a.qkv = bf.qkv; a.ld_qkv = 1536; a.vt = bf.vt; a.lens = lens; a.out = bf.att; a.ld_out = 512;
+        a.B = B; a.Tp = Tp; a.Tk = Tk;
+        a.scale_log2 = 1.4426950408889634f / std::sqrt(128.0f);
+        { ProfScope ps(ctx, PK_ATTN, s); rc = launch_attention(ctx, a, s); }
+        if (rc) return rc;
+
+        g = GemmParams{};
+        g.A = bf.att; g.lda = 512; g.W = L.w_out; g.ldw = 512; g.bias = L.b_out;
+        g.M = M; g.N = 512; g.K = 512; g.out = bf.x; g.ldo = 512;
+        g.add1 = bf.fsmn; g.ld1 = 512;
+        g.add2 = li == 0 ? nullptr : bf.x; g.ld2 = 512;
+        { ProfScope ps(ctx, PK_GEMM_OUT, s); rc = launch_gemm(ctx, g, EPI_F32_ADD, s); }
+        if (rc) return rc;
+
+        { ProfScope ps(ctx, PK_LN, s); rc = launch_ln512(ctx, bf.x, L.ln2_g, L.ln2_b, c.enc_ln_eps, M, bf.h, s); }
+        if (rc) return rc;
+
+        g = GemmParams{};
+        g.A = bf.h; g.lda = 512; g.W = L.w_ffn1; g.ldw = 512; g.bias = L.b_ffn1;
+        g.M = M; g.N = ff; g.K = 512; g.out = bf.ffn; g.ldo = ff;
+        { ProfScope ps(ctx, PK_GEMM_FFN1, s); rc = launch_gemm(ctx, g, EPI_BF16_RELU, s); }
+        if (rc) return rc;
+
+        g = GemmParams{};
+        g.A = bf.ffn; g.lda = ff; g.W = L.w_ffn2; g.ldw = ff; g.bias = L.b_ffn2;
+        g.M = M; g.N = 512; g.K = ff; g.out = bf.x; g.ldo = 512;
+        g.add1 = bf.x; g.ld1 = 512;
+        { ProfScope ps(ctx, PK_GEMM_FFN2, s); rc = launch_gemm(ctx, g, EPI_F32_ADD, s); }
+        if (rc) return rc;
+    }
+    ProfScope ps(ctx, PK_LN, s);
+    return launch_ln_final(ctx, bf.x, ctx->after_g, ctx->after_b, c.enc_ln_eps, B, Tp, lens, out, out_dtype, s);
+}
+
+}  // namespace asrfe

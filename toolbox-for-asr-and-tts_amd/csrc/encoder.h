@@ -1,0 +1,39 @@
+// Parameter blocks and launchers of the encoder's non-GEMM kernels.
+#pragma once
+
+#include "common.h"
+
+namespace asrfe {
+
+struct AttnParams {
+    const uint16_t* qkv;  // bf16 [B*Tp][ld_qkv]: q at column head*128, k at 512 + head*128
+    int ld_qkv;
+    const uint16_t* vt;   // bf16 [B][512][Tk], zero at t >= lens[b]
+    const int32_t* lens;  // [B]
+    uint16_t* out;        // bf16 [B*Tp][ld_out]
+    int ld_out;
+    int B, Tp, Tk;
+    float scale_log2;     // log2(e) / sqrt(d_k)
+};
+int32_t launch_attention(asrfe_ctx* ctx, const AttnParams& p, hipStream_t s);
+
+// pe[t][i] = sin((t+1) inv[i]) for i < D/2, cos((t+1) inv[i - D/2]) otherwise
+int32_t launch_pe_table(asrfe_ctx* ctx, const float* inv, int Tp, int D, float* pe, hipStream_t s);
+
+// h = LayerNorm(feats * xscale + pe[t]) over D columns -> bf16 [M][ldh], columns D..ldh-1 zero
+int32_t launch_ln_input(asrfe_ctx* ctx, const float* feats, const float* pe, float xscale, const float* g,
+                        const float* bta, float eps, int M, int Tp, int D, uint16_t* hout, int ldh, hipStream_t s);
+
+// h = LayerNorm(x) over 512 columns -> bf16 [M][512]
+int32_t launch_ln512(asrfe_ctx* ctx, const float* x, const float* g, const float* bta, float eps, int M, uint16_t* hout,
+                     hipStream_t s);
+
+// out = LayerNorm(x) over 512 columns, rows t >= lens[b] zero; f32 or bf16
+int32_t launch_ln_final(asrfe_ctx* ctx, const float* x, const float* g, const float* bta, float eps, int B, int Tp,
+                        const int32_t* lens, void* out, int out_dtype, hipStream_t s);
+
+// FSMN memory block on V (columns 1024..1535 of qkv) and the transposed V copy for attention
+int32_t launch_fsmn(asrfe_ctx* ctx, const uint16_t* qkv, int ld_qkv, const float* w /*[11][512]*/, const int32_t* lens,
+                    int B, int Tp, int Tk, float* fsmn /*[B*Tp][512]*/, uint16_t* vt /*[B][512][Tk]*/, hipStream_t s);
+
+}  // namespace asrfe

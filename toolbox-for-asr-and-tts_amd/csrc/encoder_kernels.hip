@@ -1,0 +1,232 @@
+// Memory-bound kernels of the SAN-M encoder on gfx950: sinusoidal position table, the LayerNorm
+// variants (one wave per row, fp32 statistics, 16-byte loads) and the FSMN memory block, which also
+// emits the transposed, length-masked copy of V that the attention kernel consumes.
+#include "common.h"
+#include "encoder.h"
+
+namespace asrfe {
+
+__device__ __forceinline__ float wave_sum(float v) {
+    v += __shfl_xor(v, 32);
+    v += __shfl_xor(v, 16);
+    v += __shfl_xor(v, 8);
+    v += __shfl_xor(v, 4);
+    v += __shfl_xor(v, 2);
+    v += __shfl_xor(v, 1);
+    return v;
+}
+
+__device__ __forceinline__ uint32_t pack_bf2(float a, float b) {
+    typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+    bf16x2 v = {static_cast<__bf16>(a), static_cast<__bf16>(b)};
+    return __builtin_bit_cast(uint32_t, v);
+}
+
+__global__ __launch_bounds__(256) void pe_kernel(const float* __restrict__ inv, int Tp, int D, float* __restrict__ pe) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int t = blockIdx.y;
+    if (i >= D) return;
+    const int half = D / 2;
+    const float pos = static_cast<float>(t + 1);
+    const float a = pos * inv[i < half ? i : i - half];
+    pe[static_cast<int64_t>(t) * D + i] = i < half ? sinf(a) : cosf(a);
+}
+
+struct LnParams {
+    const float* x;       // [M][D]
+    const float* pe;      // [Tp][D] (input mode)
+    float xscale;
+    const float* g;
+    const float* b;
+    float eps;
+    int M, Tp, D;
+    void* out;
+    int ldo;
+    const int32_t* lens;  // final mode
+};
+
+// MODE 0: x -> bf16 h.  MODE 1: (x * xscale + pe) -> bf16 h with zero pad columns.
+// MODE 2: final, f32 out, masked.  MODE 3: final, bf16 out, masked.
+template <int NV, int MODE>
+__global__ __launch_bounds__(256) void ln_kernel(const LnParams p) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= p.M) return;
+    const int nvec = p.D >> 2;
+    const float4* xr = reinterpret_cast<const float4*>(p.x + static_cast<int64_t>(row) * p.D);
+    const int t = row % p.Tp;
+    float4 v[NV];
+    float sum = 0.0f;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+        const int idx = lane + 64 * k;
+        if (idx < nvec) {
+            v[k] = xr[idx];
+            if constexpr (MODE == 1) {
+                const float4 q = reinterpret_cast<const float4*>(p.pe + static_cast<int64_t>(t) * p.D)[idx];
+                v[k].x = v[k].x * p.xscale + q.x;
+                v[k].y = v[k].y * p.xscale + q.y;
+                v[k].z = v[k].z * p.xscale + q.z;
+                v[k].w = v[k].w * p.xscale + q.w;
+            }
+            sum += (v[k].x + v[k].y) + (v[k].z + v[k].w);
+        } else {
+            v[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
+    const float mean = wave_sum(sum) / static_cast<float>(p.D);
+    float sq = 0.0f;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+        const int idx = lane + 64 * k;
+        if (idx < nvec) {
+            const float a = v[k].x - mean, b = v[k].y - mean, c = v[k].z - mean, d = v[k].w - mean;
+            sq += (a * a + b * b) + (c * c + d * d);
+        }
+    }
+    const float var = wave_sum(sq) / static_cast<float>(p.D);
+    const float rstd = 1.0f / sqrtf(var + p.eps);
+    bool live = true;
+    if constexpr (MODE >= 2) live = t < p.lens[row / p.Tp];
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+        const int idx = lane + 64 * k;
+        float4 y = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (idx < nvec && live) {
+            const float4 g = reinterpret_cast<const float4*>(p.g)[idx];
+            const float4 bb = reinterpret_cast<const float4*>(p.b)[idx];
+            y.x = (v[k].x - mean) * rstd * g.x + bb.x;
+            y.y = (v[k].y - mean) * rstd * g.y + bb.y;
+            y.z = (v[k].z - mean) * rstd * g.z + bb.z;
+            y.w = (v[k].w - mean) * rstd * g.w + bb.w;
+        }
+        if (idx < (p.ldo >> 2)) {
+            if constexpr (MODE == 2) {
+                reinterpret_cast<float4*>(reinterpret_cast<float*>(p.out) + static_cast<int64_t>(row) * p.ldo)[idx] = y;
+            } else {
+                reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(p.out) + static_cast<int64_t>(row) * p.ldo)[idx] =
+                    make_uint2(pack_bf2(y.x, y.y), pack_bf2(y.z, y.w));
+            }
+        }
+    }
+}
+
+template <int NV, int MODE>
+static int32_t launch_ln(asrfe_ctx* ctx, const LnParams& p, hipStream_t s, const char* who) {
+    if (p.M <= 0) return ASRFE_OK;
+    if (p.D % 4 != 0 || p.ldo % 4 != 0 || p.D > NV * 256 || p.ldo > NV * 256 || p.ldo < p.D)
+        return set_err(ctx, ASRFE_ERR_SHAPE, std::string(who) + ": unsupported row width");
+    hipLaunchKernelGGL((ln_kernel<NV, MODE>), dim3((p.M + 3) / 4), dim3(256), 0, s, p);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return set_err(ctx, ASRFE_ERR_HIP, std::string(who) + " launch: " + hipGetErrorString(e));
+    return ASRFE_OK;
+}
+
+int32_t launch_pe_table(asrfe_ctx* ctx, const float* inv, int Tp, int D, float* pe, hipStream_t s) {
+    if (Tp <= 0) return ASRFE_OK;
+    hipLaunchKernelGGL(pe_kernel, dim3((D + 255) / 256, Tp), dim3(256), 0, s, inv, Tp, D, pe);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return set_err(ctx, ASRFE_ERR_HIP, std::string("pe launch: ") + hipGetErrorString(e));
+    return ASRFE_OK;
+}
+
+int32_t launch_ln_input(asrfe_ctx* ctx, const float* feats, const float* pe, float xscale, const float* g,
+                        const float* bta, float eps, int M, int Tp, int D, uint16_t* hout, int ldh, hipStream_t s) {
+    LnParams p{feats, pe, xscale, g, bta, eps, M, Tp, D, hout, ldh, nullptr};
+    return launch_ln<3, 1>(ctx, p, s, "ln_input");
+}
+
+int32_t launch_ln512(asrfe_ctx* ctx, const float* x, const float* g, const float* bta, float eps, int M, uint16_t* hout,
+                     hipStream_t s) {
+    LnParams p{x, nullptr, 1.0f, g, bta, eps, M, 1, 512, hout, 512, nullptr};
+    return launch_ln<2, 0>(ctx, p, s, "ln512");
+}
+
+int32_t launch_ln_final(asrfe_ctx* ctx, const float* x, const float* g, const float* bta, float eps, int B, int Tp,
+                        const int32_t* lens, void* out, int out_dtype, hipStream_t s) {
+    LnParams p{x, nullptr, 1.0f, g, bta, eps, B * Tp, Tp, 512, out, 512, lens};
+    if (out_dtype == ASRFE_DT_BF16) return launch_ln<2, 3>(ctx, p, s, "ln_final");
+    return launch_ln<2, 2>(ctx, p, s, "ln_final");
+}
+
+// ---- FSMN memory block ----------------------------------------------------------------------------
+// fsmn[t][d] = mask_t * (sum_j w[j][d] * vm[t + j - 5][d] + vm[t][d]),  vm = v inside the utterance, else 0.
+// One workgroup handles 64 time steps x 64 channels of one utterance.
+constexpr int kFsmnTaps = 11;
+constexpr int kFsmnHalo = 5;
+constexpr int kFsmnRows = 64 + 2 * kFsmnHalo;  // 74
+constexpr int kFsmnLd = 65;
+
+__global__ __launch_bounds__(256) void fsmn_kernel(const uint16_t* __restrict__ qkv, int ld_qkv,
+                                                   const float* __restrict__ w, const int32_t* __restrict__ lens,
+                                                   int Tp, int Tk, float* __restrict__ fsmn,
+                                                   uint16_t* __restrict__ vt) {
+    __shared__ float tile[kFsmnRows * kFsmnLd];
+    __shared__ float wt[kFsmnTaps * 64];
+    const int tid = threadIdx.x;
+    const int t0 = blockIdx.x * 64, d0 = blockIdx.y * 64, b = blockIdx.z;
+    int len = lens[b];
+    len = len < 0 ? 0 : (len > Tp ? Tp : len);
+    const int64_t row0 = static_cast<int64_t>(b) * Tp;
+
+    for (int i = tid; i < kFsmnTaps * 64; i += 256) wt[i] = w[(i >> 6) * 512 + d0 + (i & 63)];
+    // rows t0-5 .. t0+68, 8 channels (16 bytes) per load
+    for (int c = tid; c < kFsmnRows * 8; c += 256) {
+        const int r = c >> 3, ch = (c & 7) * 8;
+        const int t = t0 - kFsmnHalo + r;
+        uint4 raw = make_uint4(0, 0, 0, 0);
+        if (t >= 0 && t < len)
+            raw = *reinterpret_cast<const uint4*>(qkv + (row0 + t) * ld_qkv + 1024 + d0 + ch);
+        const uint32_t wds[4] = {raw.x, raw.y, raw.z, raw.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            tile[r * kFsmnLd + ch + 2 * j] = __uint_as_float(wds[j] << 16);
+            tile[r * kFsmnLd + ch + 2 * j + 1] = __uint_as_float(wds[j] & 0xffff0000u);
+        }
+    }
+    __syncthreads();
+
+    // FSMN output: thread = (time tt, 16 consecutive channels)
+    {
+        const int tt = tid >> 2, dq = (tid & 3) * 16;
+        const int t = t0 + tt;
+        if (t < Tp) {
+            float acc[16];
+            const bool live = t < len;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[e] = tile[(tt + kFsmnHalo) * kFsmnLd + dq + e];
+#pragma unroll
+            for (int j = 0; j < kFsmnTaps; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[e] = fmaf(wt[j * 64 + dq + e], tile[(tt + j) * kFsmnLd + dq + e], acc[e]);
+            float4* o = reinterpret_cast<float4*>(fsmn + (row0 + t) * 512 + d0 + dq);
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                o[e] = live ? make_float4(acc[4 * e], acc[4 * e + 1], acc[4 * e + 2], acc[4 * e + 3])
+                            : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
+    // transposed V: thread = (channel dd, 16 consecutive time steps); masked rows are already zero in the tile
+    {
+        const int dd = tid >> 2, tq = (tid & 3) * 16;
+        uint32_t pk[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+            pk[e] = pack_bf2(tile[(kFsmnHalo + tq + 2 * e) * kFsmnLd + dd], tile[(kFsmnHalo + tq + 2 * e + 1) * kFsmnLd + dd]);
+        uint4* o = reinterpret_cast<uint4*>(vt + (static_cast<int64_t>(b) * 512 + d0 + dd) * Tk + t0 + tq);
+        o[0] = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+        o[1] = make_uint4(pk[4], pk[5], pk[6], pk[7]);
+    }
+}
+
+int32_t launch_fsmn(asrfe_ctx* ctx, const uint16_t* qkv, int ld_qkv, const float* w, const int32_t* lens, int B, int Tp,
+                    int Tk, float* fsmn, uint16_t* vt, hipStream_t s) {
+    if (B <= 0 || Tp <= 0) return ASRFE_OK;
+    if (Tk % 64 != 0 || Tk < Tp) return set_err(ctx, ASRFE_ERR_SHAPE, "fsmn: Tk must be Tp rounded up to 64");
+    hipLaunchKernelGGL(fsmn_kernel, dim3(Tk / 64, 8, B), dim3(256), 0, s, qkv, ld_qkv, w, lens, Tp, Tk, fsmn, vt);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return set_err(ctx, ASRFE_ERR_HIP, std::string("fsmn launch: ") + hipGetErrorString(e));
+    return ASRFE_OK;
+}
+
+}  // namespace asrfe

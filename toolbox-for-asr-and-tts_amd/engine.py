@@ -1,0 +1,89 @@
+"""Fixed-shape runner for the hot path: PCM batch -> fbank/LFR/CMVN -> SAN-M encoder.
+
+Stands in for the batch forward inside the reference's
+``speaker_diarization_pipeline(wav, batch_size_s=..., batch_size_token_threshold_s=40)`` call
+(/root/reference/voice-service/app/services/voice_interface.py:2049-2053): the pipeline sorts VAD
+segments by length, groups them into batches and runs frontend + encoder per batch.  ``AsrEngine``
+is one such batch slot with every buffer allocated up front, so ``run`` only enqueues kernels on the
+current stream (no allocation, no host synchronisation).
+
+Multi-GPU: utterances are independent, so a batch is split into contiguous ranges, one process and one
+engine per GPU (``shard_range``); nothing is exchanged between ranks.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from . import _lib
+from .encoder import SANMEncoder
+from .frontend import WavFrontend
+
+
+def shard_range(n_items: int, rank: int, world_size: int):
+    """Contiguous split of ``n_items`` utterances: rank r gets [lo, hi); sizes differ by at most one."""
+    if world_size < 1 or not (0 <= rank < world_size) or n_items < 0:
+        raise ValueError("shard_range: bad rank / world_size / n_items")
+    base, rem = divmod(n_items, world_size)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+class AsrEngine:
+    def __init__(self, batch: int, max_samples: int, cfg: _lib.Config | None = None, device=None,
+                 out_dtype=torch.float32, cmvn: tuple | None = None, state_dict=None):
+        self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        with torch.cuda.device(self.device):
+            self.ctx = _lib.Context(cfg)
+        c = self.ctx.cfg
+        self.frontend = WavFrontend(fs=c.sample_rate, n_mels=c.n_mels, lfr_m=c.lfr_m, lfr_n=c.lfr_n, ctx=self.ctx,
+                                    cmvn=cmvn)
+        self.encoder = SANMEncoder(input_size=c.enc_input_size, output_size=c.enc_output_size,
+                                   attention_heads=c.enc_heads, linear_units=c.enc_linear_units,
+                                   num_blocks=c.enc_num_blocks, kernel_size=c.enc_kernel_size,
+                                   sanm_shfit=c.enc_sanm_shift, ctx=self.ctx)
+        if state_dict is not None:
+            self.encoder.load_state_dict(state_dict)
+        self.batch = batch
+        self.max_samples = max_samples
+        self.t_max = self.frontend.num_frames(max_samples)
+        self.tp_max = max(1, self.frontend.num_lfr_frames(self.t_max))
+        dev = self.device
+        self.feats = torch.empty((batch, self.tp_max, c.lfr_m * c.n_mels), dtype=torch.float32, device=dev)
+        self.feat_lens = torch.zeros((batch,), dtype=torch.int32, device=dev)
+        self.out = torch.empty((batch, self.tp_max, c.enc_output_size), dtype=out_dtype, device=dev)
+        self.out_dtype = _lib.DT_BF16 if out_dtype == torch.bfloat16 else _lib.DT_F32
+        nbytes = self.encoder.workspace_bytes(batch, self.tp_max)
+        self._ws = torch.empty((nbytes + 256,), dtype=torch.uint8, device=dev)
+        self._ws_ptr = (self._ws.data_ptr() + 255) // 256 * 256
+        self._ws_bytes = nbytes
+
+    def run_frontend(self, pcm: torch.Tensor, pcm_lens: torch.Tensor):
+        """pcm [batch, >= max len] int16/float32 and pcm_lens [batch] int32, both on this device."""
+        if pcm.device != self.device or pcm_lens.device != self.device or pcm_lens.dtype != torch.int32:
+            raise ValueError("AsrEngine: pcm and pcm_lens (int32) must live on the engine's device")
+        if pcm.dim() != 2 or pcm.shape[0] != self.batch or pcm.shape[1] > self.max_samples or pcm.stride(1) != 1:
+            raise ValueError("AsrEngine: pcm must be [batch, n <= max_samples] with unit inner stride")
+        dt = {torch.int16: _lib.PCM_I16, torch.float32: _lib.PCM_F32}.get(pcm.dtype)
+        if dt is None:
+            raise ValueError("AsrEngine: PCM dtype must be int16 or float32")
+        stream = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        self.ctx.check(self.ctx.lib.asrfe_frontend(self.ctx.handle, pcm.data_ptr(), dt, pcm.stride(0),
+                                                   pcm_lens.data_ptr(), self.batch, self.tp_max,
+                                                   self.feats.data_ptr(), _lib.DT_F32, self.feat_lens.data_ptr(),
+                                                   stream))
+        return self.feats, self.feat_lens
+
+    def run_encoder(self):
+        stream = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        self.ctx.check(self.ctx.lib.asrfe_encoder_forward(self.ctx.handle, self.feats.data_ptr(),
+                                                          self.feat_lens.data_ptr(), self.batch, self.tp_max,
+                                                          self.out.data_ptr(), self.out_dtype, self._ws_ptr,
+                                                          self._ws_bytes, stream))
+        return self.out, self.feat_lens
+
+    def run(self, pcm: torch.Tensor, pcm_lens: torch.Tensor):
+        """One step of the hot path; returns (encoder_out [batch, T', 512], out_lens [batch]) views of engine buffers."""
+        self.run_frontend(pcm, pcm_lens)
+        return self.run_encoder()

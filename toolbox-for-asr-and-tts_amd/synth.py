@@ -1,0 +1,47 @@
+"""Seeded synthetic inputs for benchmarks: 16 kHz int16 PCM clips and random-init encoder weights.
+
+No dataset or checkpoint is reachable offline, so throughput is measured on synthetic data of the real
+shape: Gaussian PCM (sigma 3000, speech-like crest) whose first 10 % is exact zeros (log-floor frames),
+and N(0, 0.02) weights / LayerNorm gamma 1, beta 0 under FunASR's ``SANMEncoder`` state_dict names.
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+
+def bench_pcm(batch: int, n_samples: int, seed: int) -> np.ndarray:
+    rng = np.random.default_rng(seed)
+    x = rng.normal(0.0, 3000.0, size=(batch, n_samples)).astype(np.float32)
+    x[:, : n_samples // 10] = 0.0
+    return np.clip(np.rint(x), -32768, 32767).astype(np.int16)
+
+
+def encoder_state_dict(num_blocks: int = 50, input_size: int = 560, d: int = 512, ff: int = 2048, kernel: int = 11,
+                       seed: int = 0, std: float = 0.02):
+    g = torch.Generator(device="cpu")
+    g.manual_seed(seed)
+
+    def rnd(*shape):
+        return torch.randn(*shape, generator=g, dtype=torch.float32) * std
+
+    sd = {}
+    for li in range(num_blocks):
+        p = "encoders0.0" if li == 0 else f"encoders.{li - 1}"
+        din = input_size if li == 0 else d
+        sd[f"{p}.norm1.weight"] = torch.ones(din)
+        sd[f"{p}.norm1.bias"] = torch.zeros(din)
+        sd[f"{p}.self_attn.linear_q_k_v.weight"] = rnd(3 * d, din)
+        sd[f"{p}.self_attn.linear_q_k_v.bias"] = rnd(3 * d)
+        sd[f"{p}.self_attn.fsmn_block.weight"] = rnd(d, 1, kernel)
+        sd[f"{p}.self_attn.linear_out.weight"] = rnd(d, d)
+        sd[f"{p}.self_attn.linear_out.bias"] = rnd(d)
+        sd[f"{p}.norm2.weight"] = torch.ones(d)
+        sd[f"{p}.norm2.bias"] = torch.zeros(d)
+        sd[f"{p}.feed_forward.w_1.weight"] = rnd(ff, d)
+        sd[f"{p}.feed_forward.w_1.bias"] = rnd(ff)
+        sd[f"{p}.feed_forward.w_2.weight"] = rnd(d, ff)
+        sd[f"{p}.feed_forward.w_2.bias"] = rnd(d)
+    sd["after_norm.weight"] = torch.ones(d)
+    sd["after_norm.bias"] = torch.zeros(d)
+    return sd
