@@ -140,7 +140,7 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "bf16",
+            "dtype": "f16",
             "data": "synthetic",
             "config": {
                 "workload": f"fbank+LFR+CMVN+SAN-M encoder (50 blocks, d=512), {args.batch} x 30 s int16 utterances "

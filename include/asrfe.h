@@ -55,6 +55,7 @@ extern "C" {
 
 #define ASRFE_DT_F32 0
 #define ASRFE_DT_BF16 1
+#define ASRFE_DT_F16 2
 
 typedef struct asrfe_ctx asrfe_ctx;
 
@@ -79,6 +80,9 @@ typedef struct asrfe_config {
     int32_t enc_kernel_size; /* 11 */
     int32_t enc_sanm_shift;  /* 0 */
     float enc_ln_eps;        /* 1e-12 */
+    int32_t enc_compute_dtype; /* 16-bit type of the MFMA operands (weights, activations, P): ASRFE_DT_F16
+                                  (default: meets the 1e-2 parity bar) or ASRFE_DT_BF16 (same MFMA rate, ~8x the
+                                  rounding error); accumulation, residual stream, LayerNorm and softmax are fp32 */
 } asrfe_config;
 
 /* One named host tensor of an encoder state_dict (FunASR key names without the "encoder." prefix). */
@@ -128,7 +132,7 @@ int32_t asrfe_frontend(asrfe_ctx* ctx, const void* pcm, int32_t pcm_dtype, int64
 int64_t asrfe_encoder_workspace_bytes(const asrfe_ctx* ctx, int32_t batch, int32_t tp);
 
 /* SANMEncoder.forward: feats [B, tp, 560] float32, lens [B] int32 -> out [B, tp, 512]
- * (float32 or bf16), rows t >= lens[b] zero.  workspace: >= asrfe_encoder_workspace_bytes, 256-B aligned. */
+ * (ASRFE_DT_F32, _BF16 or _F16), rows t >= lens[b] zero.  workspace: >= asrfe_encoder_workspace_bytes, 256-B aligned. */
 int32_t asrfe_encoder_forward(asrfe_ctx* ctx, const float* feats, const int32_t* lens, int32_t batch,
                               int32_t tp, void* out, int32_t out_dtype, void* workspace,
                               int64_t workspace_bytes, void* stream);

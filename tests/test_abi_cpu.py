@@ -44,6 +44,7 @@ def test_default_config_is_paraformer_large(pkg):
     assert (c.lfr_m, c.lfr_n) == (7, 6)
     assert (c.enc_input_size, c.enc_output_size, c.enc_heads, c.enc_linear_units, c.enc_num_blocks) == (560, 512, 4, 2048, 50)
     assert c.enc_kernel_size == 11 and c.enc_sanm_shift == 0
+    assert c.enc_compute_dtype == pkg._lib.DT_F16
     assert abs(c.preemph - 0.97) < 1e-7 and abs(c.enc_ln_eps - 1e-12) < 1e-18
 
 

@@ -17,7 +17,9 @@ from oracle import sanm_oracle as so
 pytestmark = pytest.mark.gpu
 
 FBANK_TOL = 1e-3
-ENC_TOL = 1e-2
+ENC_TOL = 1e-2       # the stated bar; met with fp16 MFMA operands (the default compute dtype)
+ENC_TOL_BF16 = 6e-2  # bf16 operands: rounding alone gives 1.7e-2 (2 blocks) .. 3.1e-2 (50 blocks) on these
+#                      fixtures in a CPU emulation with exact accumulation, so this mode is below the bar
 GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
 
 
@@ -132,10 +134,10 @@ def test_fbank_analytic_known_answers(fe):
     floor = math.log(fo.LOG_FLOOR)
     z = np.zeros((1, 16000), np.int16)
     out, _ = fe.forward_fbank(dev(z), [16000])
-    assert torch.all(out == np.float32(floor))
+    assert torch.all(out == out[0, 0, 0]) and abs(float(out[0, 0, 0]) - floor) < 1e-5
     dc = np.full((1, 16000), 1234, np.int16)
-    out, _ = fe.forward_fbank(dev(dc), [16000])
-    assert torch.all(out == np.float32(floor)), "a constant signal must vanish after DC removal"
+    out_dc, _ = fe.forward_fbank(dev(dc), [16000])
+    assert torch.equal(out_dc, out), "a constant signal must vanish after DC removal"
     t = np.arange(16000) / 16000.0
     tone = np.rint(8000 * np.sin(2 * np.pi * 1000.0 * t)).astype(np.int16)[None]
     out, _ = fe.forward_fbank(dev(tone), [16000])
@@ -153,7 +155,8 @@ def test_fbank_full_size_properties(fe):
     assert out.shape == (b, 2998, 80) and nfr.cpu().tolist() == [2998] * b
     assert bool(torch.isfinite(out).all())
     # (1) the zero prefix (first 10 %) sits exactly on the log floor
-    assert torch.all(out[:, : (n // 10 - 400) // 160] == np.float32(math.log(fo.LOG_FLOOR)))
+    zp = out[:, : (n // 10 - 400) // 160]
+    assert torch.all(zp == zp[0, 0, 0]) and abs(float(zp[0, 0, 0]) - math.log(fo.LOG_FLOOR)) < 1e-5
     # (2) shifting the signal by one hop shifts the frames by one, bit for bit
     shifted = torch.zeros_like(x)
     shifted[:, : n - 160] = x[:, 160:]
@@ -194,10 +197,10 @@ def test_bad_arguments_raise(pkg, fe):
 
 
 # ---- encoder ---------------------------------------------------------------------------------------
-def run_encoder(pkg, num_blocks, seed, feats, lens, out_dtype=torch.float32):
+def run_encoder(pkg, num_blocks, seed, feats, lens, out_dtype=torch.float32, compute_dtype="float16"):
     cfg = so.SanmConfig(num_blocks=num_blocks)
     sd = so.make_state_dict(cfg, seed=seed, dtype=torch.float32)
-    enc = pkg.SANMEncoder(num_blocks=num_blocks)
+    enc = pkg.SANMEncoder(num_blocks=num_blocks, compute_dtype=compute_dtype)
     enc.load_state_dict(sd)
     out, olens, _ = enc.forward(feats.to("cuda"), lens, out_dtype=out_dtype)
     torch.cuda.synchronize()
@@ -213,6 +216,22 @@ def test_encoder_tiny_golden(pkg):
     err = np.max(np.abs(got - g["out"]))
     assert err <= ENC_TOL, err
     assert np.all(got[1, int(g["lens"][1]):] == 0.0)
+
+
+def test_encoder_bf16_mode(pkg):
+    """bf16 MFMA operands are selectable; their error is rounding-limited and checked against a looser bound."""
+    g = np.load(os.path.join(GOLDEN, "encoder_tiny.npz"))
+    feats = torch.from_numpy(g["feats"])
+    out, _, _, _ = run_encoder(pkg, int(g["num_blocks"]), int(g["seed"]), feats, torch.from_numpy(g["lens"]),
+                               compute_dtype="bfloat16")
+    err = np.max(np.abs(out.cpu().numpy() - g["out"]))
+    assert err <= ENC_TOL_BF16, err
+    g = np.load(os.path.join(GOLDEN, "encoder_probe_50l.npz"))
+    feats = so.synth_feats(2, 96, 560, seed=int(g["feats_seed"]))
+    out, _, _, _ = run_encoder(pkg, 50, int(g["seed"]), feats, torch.from_numpy(g["lens"]), compute_dtype="bfloat16")
+    got = out.cpu().numpy()
+    e = max(np.max(np.abs(got[0, [0, 1, 47, 95]] - g["rows_b0"])), np.max(np.abs(got[1, [0, 30, 60]] - g["rows_b1"])))
+    assert e <= ENC_TOL_BF16, e
 
 
 def test_encoder_one_layer_vs_oracle_various_lengths(pkg):
@@ -258,6 +277,8 @@ def test_encoder_full_length_properties(pkg):
     assert torch.equal(out3.flip(0), out)
     outb, _, _ = enc.forward(feats.cuda(), lens, out_dtype=torch.bfloat16)
     assert torch.equal(outb, out.to(torch.bfloat16))
+    outh, _, _ = enc.forward(feats.cuda(), lens, out_dtype=torch.float16)
+    assert torch.equal(outh, out.to(torch.float16))
     assert float(out[1, 333:].abs().max()) == 0.0 and float(out[2, 64:].abs().max()) == 0.0
 
 

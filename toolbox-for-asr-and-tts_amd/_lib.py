@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libasrfe.so")
 
 PCM_I16, PCM_F32 = 0, 1
-DT_F32, DT_BF16 = 0, 1
+DT_F32, DT_BF16, DT_F16 = 0, 1, 2
 
 ERROR_NAMES = {
     0: "OK",
@@ -53,6 +53,7 @@ class Config(C.Structure):
         ("enc_kernel_size", C.c_int32),
         ("enc_sanm_shift", C.c_int32),
         ("enc_ln_eps", C.c_float),
+        ("enc_compute_dtype", C.c_int32),
     ]
 
 

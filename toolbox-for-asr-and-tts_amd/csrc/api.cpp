@@ -51,6 +51,7 @@ extern "C" int32_t asrfe_default_config(asrfe_config* c) {
     c->enc_kernel_size = 11;
     c->enc_sanm_shift = 0;
     c->enc_ln_eps = 1e-12f;
+    c->enc_compute_dtype = ASRFE_DT_F16;
     return ASRFE_OK;
 }
 
@@ -142,6 +143,7 @@ static int32_t check_config(const asrfe_config& c, std::string& why) {
     if (c.enc_kernel_size != 11 || c.enc_sanm_shift != 0) { why = "only FSMN kernel 11 / shift 0 is built"; return ASRFE_ERR_BAD_ARG; }
     if (c.enc_input_size < 8 || c.enc_input_size > 640 || c.enc_input_size % 8 != 0) { why = "enc_input_size must be a multiple of 8 in 8..640"; return ASRFE_ERR_BAD_ARG; }
     if (c.enc_num_blocks < 1) { why = "enc_num_blocks must be >= 1"; return ASRFE_ERR_BAD_ARG; }
+    if (c.enc_compute_dtype != ASRFE_DT_F16 && c.enc_compute_dtype != ASRFE_DT_BF16) { why = "enc_compute_dtype must be ASRFE_DT_F16 or ASRFE_DT_BF16"; return ASRFE_ERR_BAD_ARG; }
     return ASRFE_OK;
 }
 
@@ -333,12 +335,20 @@ static int32_t up_f32(asrfe_ctx* ctx, const HostTensor* t, float** dev) {
     return upload(ctx, v, dev);
 }
 
-// [n][k] float -> bf16 [n][k_pad] with zero columns past k
+static uint16_t f16_rne(float f) {
+    const _Float16 h = static_cast<_Float16>(f);
+    uint16_t u;
+    std::memcpy(&u, &h, 2);
+    return u;
+}
+
+// [n][k] float -> 16-bit [n][k_pad] (bf16 or fp16 per the context) with zero columns past k
 static int32_t up_bf16(asrfe_ctx* ctx, const HostTensor* t, int k_pad, uint16_t** dev) {
     const int64_t n = t->shape[0], k = t->shape[1];
+    const bool f16 = ctx->cfg.enc_compute_dtype == ASRFE_DT_F16;
     std::vector<uint16_t> v(static_cast<size_t>(n) * k_pad, 0);
     for (int64_t r = 0; r < n; ++r)
-        for (int64_t c = 0; c < k; ++c) v[r * k_pad + c] = bf16_rne(t->data[r * k + c]);
+        for (int64_t c = 0; c < k; ++c) v[r * k_pad + c] = f16 ? f16_rne(t->data[r * k + c]) : bf16_rne(t->data[r * k + c]);
     return upload(ctx, v, dev);
 }
 
@@ -487,7 +497,7 @@ extern "C" int32_t asrfe_encoder_forward(asrfe_ctx* ctx, const float* feats, con
     if (batch == 0 || tp == 0) return ASRFE_OK;
     if (static_cast<int64_t>(batch) * tp > (1 << 24)) return set_err(ctx, ASRFE_ERR_SHAPE, "asrfe_encoder_forward: batch * tp too large");
     if (!feats || !lens || !out || !workspace) return set_err(ctx, ASRFE_ERR_BAD_ARG, "asrfe_encoder_forward: null argument");
-    if (out_dtype != ASRFE_DT_F32 && out_dtype != ASRFE_DT_BF16) return set_err(ctx, ASRFE_ERR_BAD_ARG, "asrfe_encoder_forward: bad out_dtype");
+    if (out_dtype != ASRFE_DT_F32 && out_dtype != ASRFE_DT_BF16 && out_dtype != ASRFE_DT_F16) return set_err(ctx, ASRFE_ERR_BAD_ARG, "asrfe_encoder_forward: bad out_dtype");
     if (reinterpret_cast<uintptr_t>(workspace) % 256 != 0) return set_err(ctx, ASRFE_ERR_WORKSPACE, "asrfe_encoder_forward: workspace must be 256-byte aligned");
     if (reinterpret_cast<uintptr_t>(feats) % 16 != 0 || reinterpret_cast<uintptr_t>(out) % 16 != 0)
         return set_err(ctx, ASRFE_ERR_BAD_ARG, "asrfe_encoder_forward: feats / out must be 16-byte aligned");

@@ -12,13 +12,10 @@
 //   FSMN kernel) and is register-staged into rows padded to 136 bytes so that the 8-byte fragment
 //   reads of 32 lanes hit 32 different bank pairs.
 #include "common.h"
+#include "elem.h"
 #include "encoder.h"
 
 namespace asrfe {
-
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
-typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
-typedef __attribute__((ext_vector_type(16))) float f32x16;
 
 constexpr int kAttnThreads = 256;
 constexpr int kKTileBytes = 64 * 256;      // 64 keys x 128 d bf16
@@ -29,12 +26,7 @@ constexpr int kVTileBytes = 128 * kVRow;
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gptr),       \
                                      (__attribute__((address_space(3))) void*)(lptr), 16, 0, 0)
 
-__device__ __forceinline__ uint32_t pack2(float a, float b) {
-    typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
-    bf16x2 v = {static_cast<__bf16>(a), static_cast<__bf16>(b)};
-    return __builtin_bit_cast(uint32_t, v);
-}
-
+template <bool F16>
 __global__ __launch_bounds__(kAttnThreads) void attn_kernel(const AttnParams p) {
     __shared__ __attribute__((aligned(16))) char smem[kKTileBytes + kVTileBytes];
     char* ks = smem;
@@ -52,13 +44,13 @@ __global__ __launch_bounds__(kAttnThreads) void attn_kernel(const AttnParams p) 
     const int n_kt = (len + 63) >> 6;
 
     // Q fragments: lane holds Q[q0 + l31][16 s + 8 h .. +8), s = 0..7
-    bf16x8 qf[8];
+    u16x8 qf[8];
     {
         int qr = q0 + l31;
         qr = qr < p.Tp ? qr : p.Tp - 1;
         const uint16_t* qp = p.qkv + (row0 + qr) * p.ld_qkv + head * 128 + 8 * h;
 #pragma unroll
-        for (int s = 0; s < 8; ++s) qf[s] = *reinterpret_cast<const bf16x8*>(qp + 16 * s);
+        for (int s = 0; s < 8; ++s) qf[s] = *reinterpret_cast<const u16x8*>(qp + 16 * s);
     }
 
     f32x16 oacc[4];
@@ -104,8 +96,8 @@ __global__ __launch_bounds__(kAttnThreads) void attn_kernel(const AttnParams p) 
             const char* krow = ks + (kk * 32 + l31) * 256;
 #pragma unroll
             for (int s = 0; s < 8; ++s) {
-                const bf16x8 kf = *reinterpret_cast<const bf16x8*>(krow + (((2 * s + h) ^ (l31 & 15)) << 4));
-                sacc[kk] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[s], sacc[kk], 0, 0, 0);
+                const u16x8 kf = *reinterpret_cast<const u16x8*>(krow + (((2 * s + h) ^ (l31 & 15)) << 4));
+                sacc[kk] = mfma32<F16>(kf, qf[s], sacc[kk]);
             }
         }
         if (kt == n_kt - 1) {  // wave-uniform: mask keys at or past the utterance length
@@ -128,7 +120,7 @@ __global__ __launch_bounds__(kAttnThreads) void attn_kernel(const AttnParams p) 
         const float mc = m_new * c;
         m_run = m_new;
         float psum = 0.0f;
-        bf16x8 pf[2][2];
+        u16x8 pf[2][2];
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
@@ -137,7 +129,7 @@ __global__ __launch_bounds__(kAttnThreads) void attn_kernel(const AttnParams p) 
                 for (int j = 0; j < 8; ++j) {
                     const float pv = __builtin_amdgcn_exp2f(sacc[kk][8 * s2 + j] * c - mc);
                     psum += pv;
-                    pf[kk][s2][j] = static_cast<__bf16>(pv);
+                    pf[kk][s2][j] = to_elem<F16>(pv);
                 }
         l_run = l_run * alpha + psum;
 #pragma unroll
@@ -154,10 +146,10 @@ __global__ __launch_bounds__(kAttnThreads) void attn_kernel(const AttnParams p) 
 #pragma unroll
                 for (int s2 = 0; s2 < 2; ++s2) {
                     // element j of the fragment is key 32 kk + 16 s2 + 8 (j >> 2) + 4 h + (j & 3)
-                    const bf16x4 lo = *reinterpret_cast<const bf16x4*>(vrow + (kk * 32 + s2 * 16) * 2);
-                    const bf16x4 hi = *reinterpret_cast<const bf16x4*>(vrow + (kk * 32 + s2 * 16 + 8) * 2);
-                    const bf16x8 vf = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-                    oacc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[kk][s2], oacc[mt], 0, 0, 0);
+                    const u16x4 lo = *reinterpret_cast<const u16x4*>(vrow + (kk * 32 + s2 * 16) * 2);
+                    const u16x4 hi = *reinterpret_cast<const u16x4*>(vrow + (kk * 32 + s2 * 16 + 8) * 2);
+                    const u16x8 vf = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+                    oacc[mt] = mfma32<F16>(vf, pf[kk][s2], oacc[mt]);
                 }
         }
     }
@@ -172,10 +164,10 @@ __global__ __launch_bounds__(kAttnThreads) void attn_kernel(const AttnParams p) 
     for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
         for (int gp = 0; gp < 2; ++gp) {
-            uint32_t lo0 = pack2(oacc[mt][8 * gp] * inv, oacc[mt][8 * gp + 1] * inv);
-            uint32_t lo1 = pack2(oacc[mt][8 * gp + 2] * inv, oacc[mt][8 * gp + 3] * inv);
-            uint32_t hi0 = pack2(oacc[mt][8 * gp + 4] * inv, oacc[mt][8 * gp + 5] * inv);
-            uint32_t hi1 = pack2(oacc[mt][8 * gp + 6] * inv, oacc[mt][8 * gp + 7] * inv);
+            uint32_t lo0 = pack_elem2<F16>(oacc[mt][8 * gp] * inv, oacc[mt][8 * gp + 1] * inv);
+            uint32_t lo1 = pack_elem2<F16>(oacc[mt][8 * gp + 2] * inv, oacc[mt][8 * gp + 3] * inv);
+            uint32_t hi0 = pack_elem2<F16>(oacc[mt][8 * gp + 4] * inv, oacc[mt][8 * gp + 5] * inv);
+            uint32_t hi1 = pack_elem2<F16>(oacc[mt][8 * gp + 6] * inv, oacc[mt][8 * gp + 7] * inv);
             auto s0 = __builtin_amdgcn_permlane32_swap(lo0, hi0, false, false);
             auto s1 = __builtin_amdgcn_permlane32_swap(lo1, hi1, false, false);
             if (ok) *reinterpret_cast<uint4*>(orow + mt * 32 + 16 * gp + 8 * h) = make_uint4(s0[0], s1[0], s0[1], s1[1]);
@@ -186,7 +178,8 @@ int32_t launch_attention(asrfe_ctx* ctx, const AttnParams& p, hipStream_t s) {
     if (p.B <= 0 || p.Tp <= 0) return ASRFE_OK;
     if (p.Tk % 64 != 0 || p.Tk < p.Tp) return set_err(ctx, ASRFE_ERR_SHAPE, "attention: Tk must be Tp rounded up to 64");
     dim3 grid((p.Tp + 127) / 128, 4, p.B);
-    hipLaunchKernelGGL(attn_kernel, grid, dim3(kAttnThreads), 0, s, p);
+    if (ctx->cfg.enc_compute_dtype == ASRFE_DT_F16) hipLaunchKernelGGL(attn_kernel<true>, grid, dim3(kAttnThreads), 0, s, p);
+    else hipLaunchKernelGGL(attn_kernel<false>, grid, dim3(kAttnThreads), 0, s, p);
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) return set_err(ctx, ASRFE_ERR_HIP, std::string("attention launch: ") + hipGetErrorString(e));
     return ASRFE_OK;

@@ -1,0 +1,58 @@
+// 16-bit element types of the encoder's MFMA operands: bf16 or IEEE fp16 (same MFMA rate on gfx950).
+// Storage is uint16_t everywhere; F16 = true selects fp16.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace asrfe {
+
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+typedef __attribute__((ext_vector_type(8))) uint16_t u16x8;
+typedef __attribute__((ext_vector_type(4))) uint16_t u16x4;
+
+template <bool F16>
+__device__ __forceinline__ uint16_t to_elem(float v) {
+    if constexpr (F16) return __builtin_bit_cast(uint16_t, static_cast<_Float16>(v));
+    else return __builtin_bit_cast(uint16_t, static_cast<__bf16>(v));
+}
+
+template <bool F16>
+__device__ __forceinline__ uint32_t pack_elem2(float a, float b) {
+    if constexpr (F16) {
+        typedef __attribute__((ext_vector_type(2))) _Float16 h2;
+        h2 v = {static_cast<_Float16>(a), static_cast<_Float16>(b)};
+        return __builtin_bit_cast(uint32_t, v);
+    } else {
+        typedef __attribute__((ext_vector_type(2))) __bf16 b2;
+        b2 v = {static_cast<__bf16>(a), static_cast<__bf16>(b)};
+        return __builtin_bit_cast(uint32_t, v);
+    }
+}
+
+// two packed elements (low half = first) -> floats
+template <bool F16>
+__device__ __forceinline__ void unpack_elem2(uint32_t w, float& lo, float& hi) {
+    if constexpr (F16) {
+        typedef __attribute__((ext_vector_type(2))) _Float16 h2;
+        const h2 v = __builtin_bit_cast(h2, w);
+        lo = static_cast<float>(v[0]);
+        hi = static_cast<float>(v[1]);
+    } else {
+        lo = __uint_as_float(w << 16);
+        hi = __uint_as_float(w & 0xffff0000u);
+    }
+}
+
+// D = A (32 x 16) * B (16 x 32) + C on the matrix cores; operands are 8 consecutive k per lane.
+template <bool F16>
+__device__ __forceinline__ f32x16 mfma32(const u16x8 a, const u16x8 b, const f32x16 c) {
+    if constexpr (F16)
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+    else
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+
+}  // namespace asrfe

@@ -2,6 +2,7 @@
 // variants (one wave per row, fp32 statistics, 16-byte loads) and the FSMN memory block, which also
 // emits the transposed, length-masked copy of V that the attention kernel consumes.
 #include "common.h"
+#include "elem.h"
 #include "encoder.h"
 
 namespace asrfe {
@@ -14,12 +15,6 @@ __device__ __forceinline__ float wave_sum(float v) {
     v += __shfl_xor(v, 2);
     v += __shfl_xor(v, 1);
     return v;
-}
-
-__device__ __forceinline__ uint32_t pack_bf2(float a, float b) {
-    typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
-    bf16x2 v = {static_cast<__bf16>(a), static_cast<__bf16>(b)};
-    return __builtin_bit_cast(uint32_t, v);
 }
 
 __global__ __launch_bounds__(256) void pe_kernel(const float* __restrict__ inv, int Tp, int D, float* __restrict__ pe) {
@@ -45,9 +40,9 @@ struct LnParams {
     const int32_t* lens;  // final mode
 };
 
-// MODE 0: x -> bf16 h.  MODE 1: (x * xscale + pe) -> bf16 h with zero pad columns.
-// MODE 2: final, f32 out, masked.  MODE 3: final, bf16 out, masked.
-template <int NV, int MODE>
+// MODE 0: x -> 16-bit h.  MODE 1: (x * xscale + pe) -> 16-bit h with zero pad columns.
+// MODE 2: final, f32 out, masked.  MODE 3: final, 16-bit out, masked.  F16 picks fp16 over bf16.
+template <int NV, int MODE, bool F16>
 __global__ __launch_bounds__(256) void ln_kernel(const LnParams p) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -105,18 +100,19 @@ __global__ __launch_bounds__(256) void ln_kernel(const LnParams p) {
                 reinterpret_cast<float4*>(reinterpret_cast<float*>(p.out) + static_cast<int64_t>(row) * p.ldo)[idx] = y;
             } else {
                 reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(p.out) + static_cast<int64_t>(row) * p.ldo)[idx] =
-                    make_uint2(pack_bf2(y.x, y.y), pack_bf2(y.z, y.w));
+                    make_uint2(pack_elem2<F16>(y.x, y.y), pack_elem2<F16>(y.z, y.w));
             }
         }
     }
 }
 
 template <int NV, int MODE>
-static int32_t launch_ln(asrfe_ctx* ctx, const LnParams& p, hipStream_t s, const char* who) {
+static int32_t launch_ln(asrfe_ctx* ctx, const LnParams& p, bool f16, hipStream_t s, const char* who) {
     if (p.M <= 0) return ASRFE_OK;
     if (p.D % 4 != 0 || p.ldo % 4 != 0 || p.D > NV * 256 || p.ldo > NV * 256 || p.ldo < p.D)
         return set_err(ctx, ASRFE_ERR_SHAPE, std::string(who) + ": unsupported row width");
-    hipLaunchKernelGGL((ln_kernel<NV, MODE>), dim3((p.M + 3) / 4), dim3(256), 0, s, p);
+    if (f16) hipLaunchKernelGGL((ln_kernel<NV, MODE, true>), dim3((p.M + 3) / 4), dim3(256), 0, s, p);
+    else hipLaunchKernelGGL((ln_kernel<NV, MODE, false>), dim3((p.M + 3) / 4), dim3(256), 0, s, p);
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) return set_err(ctx, ASRFE_ERR_HIP, std::string(who) + " launch: " + hipGetErrorString(e));
     return ASRFE_OK;
@@ -133,20 +129,21 @@ int32_t launch_pe_table(asrfe_ctx* ctx, const float* inv, int Tp, int D, float* 
 int32_t launch_ln_input(asrfe_ctx* ctx, const float* feats, const float* pe, float xscale, const float* g,
                         const float* bta, float eps, int M, int Tp, int D, uint16_t* hout, int ldh, hipStream_t s) {
     LnParams p{feats, pe, xscale, g, bta, eps, M, Tp, D, hout, ldh, nullptr};
-    return launch_ln<3, 1>(ctx, p, s, "ln_input");
+    return launch_ln<3, 1>(ctx, p, ctx->cfg.enc_compute_dtype == ASRFE_DT_F16, s, "ln_input");
 }
 
 int32_t launch_ln512(asrfe_ctx* ctx, const float* x, const float* g, const float* bta, float eps, int M, uint16_t* hout,
                      hipStream_t s) {
     LnParams p{x, nullptr, 1.0f, g, bta, eps, M, 1, 512, hout, 512, nullptr};
-    return launch_ln<2, 0>(ctx, p, s, "ln512");
+    return launch_ln<2, 0>(ctx, p, ctx->cfg.enc_compute_dtype == ASRFE_DT_F16, s, "ln512");
 }
 
 int32_t launch_ln_final(asrfe_ctx* ctx, const float* x, const float* g, const float* bta, float eps, int B, int Tp,
                         const int32_t* lens, void* out, int out_dtype, hipStream_t s) {
     LnParams p{x, nullptr, 1.0f, g, bta, eps, B * Tp, Tp, 512, out, 512, lens};
-    if (out_dtype == ASRFE_DT_BF16) return launch_ln<2, 3>(ctx, p, s, "ln_final");
-    return launch_ln<2, 2>(ctx, p, s, "ln_final");
+    if (out_dtype == ASRFE_DT_BF16) return launch_ln<2, 3>(ctx, p, false, s, "ln_final");
+    if (out_dtype == ASRFE_DT_F16) return launch_ln<2, 3>(ctx, p, true, s, "ln_final");
+    return launch_ln<2, 2>(ctx, p, false, s, "ln_final");
 }
 
 // ---- FSMN memory block ----------------------------------------------------------------------------
@@ -157,6 +154,7 @@ constexpr int kFsmnHalo = 5;
 constexpr int kFsmnRows = 64 + 2 * kFsmnHalo;  // 74
 constexpr int kFsmnLd = 65;
 
+template <bool F16>
 __global__ __launch_bounds__(256) void fsmn_kernel(const uint16_t* __restrict__ qkv, int ld_qkv,
                                                    const float* __restrict__ w, const int32_t* __restrict__ lens,
                                                    int Tp, int Tk, float* __restrict__ fsmn,
@@ -179,10 +177,8 @@ __global__ __launch_bounds__(256) void fsmn_kernel(const uint16_t* __restrict__ 
             raw = *reinterpret_cast<const uint4*>(qkv + (row0 + t) * ld_qkv + 1024 + d0 + ch);
         const uint32_t wds[4] = {raw.x, raw.y, raw.z, raw.w};
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            tile[r * kFsmnLd + ch + 2 * j] = __uint_as_float(wds[j] << 16);
-            tile[r * kFsmnLd + ch + 2 * j + 1] = __uint_as_float(wds[j] & 0xffff0000u);
-        }
+        for (int j = 0; j < 4; ++j)
+            unpack_elem2<F16>(wds[j], tile[r * kFsmnLd + ch + 2 * j], tile[r * kFsmnLd + ch + 2 * j + 1]);
     }
     __syncthreads();
 
@@ -212,7 +208,7 @@ __global__ __launch_bounds__(256) void fsmn_kernel(const uint16_t* __restrict__ 
         uint32_t pk[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e)
-            pk[e] = pack_bf2(tile[(kFsmnHalo + tq + 2 * e) * kFsmnLd + dd], tile[(kFsmnHalo + tq + 2 * e + 1) * kFsmnLd + dd]);
+            pk[e] = pack_elem2<F16>(tile[(kFsmnHalo + tq + 2 * e) * kFsmnLd + dd], tile[(kFsmnHalo + tq + 2 * e + 1) * kFsmnLd + dd]);
         uint4* o = reinterpret_cast<uint4*>(vt + (static_cast<int64_t>(b) * 512 + d0 + dd) * Tk + t0 + tq);
         o[0] = make_uint4(pk[0], pk[1], pk[2], pk[3]);
         o[1] = make_uint4(pk[4], pk[5], pk[6], pk[7]);
@@ -223,7 +219,10 @@ int32_t launch_fsmn(asrfe_ctx* ctx, const uint16_t* qkv, int ld_qkv, const float
                     int Tk, float* fsmn, uint16_t* vt, hipStream_t s) {
     if (B <= 0 || Tp <= 0) return ASRFE_OK;
     if (Tk % 64 != 0 || Tk < Tp) return set_err(ctx, ASRFE_ERR_SHAPE, "fsmn: Tk must be Tp rounded up to 64");
-    hipLaunchKernelGGL(fsmn_kernel, dim3(Tk / 64, 8, B), dim3(256), 0, s, qkv, ld_qkv, w, lens, Tp, Tk, fsmn, vt);
+    if (ctx->cfg.enc_compute_dtype == ASRFE_DT_F16)
+        hipLaunchKernelGGL(fsmn_kernel<true>, dim3(Tk / 64, 8, B), dim3(256), 0, s, qkv, ld_qkv, w, lens, Tp, Tk, fsmn, vt);
+    else
+        hipLaunchKernelGGL(fsmn_kernel<false>, dim3(Tk / 64, 8, B), dim3(256), 0, s, qkv, ld_qkv, w, lens, Tp, Tk, fsmn, vt);
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) return set_err(ctx, ASRFE_ERR_HIP, std::string("fsmn launch: ") + hipGetErrorString(e));
     return ASRFE_OK;

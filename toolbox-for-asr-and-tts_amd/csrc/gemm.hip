@@ -14,12 +14,10 @@
 //   Workgroup ids are remapped so that the 8 XCDs each walk a contiguous range of tiles (their L2s
 //   are private): the tiles that share an activation panel run on the same XCD at about the same time.
 #include "common.h"
+#include "elem.h"
 #include "gemm.h"
 
 namespace asrfe {
-
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
-typedef __attribute__((ext_vector_type(16))) float f32x16;
 
 constexpr int BM = 256, BN = 256, BK = 64;
 constexpr int kGemmThreads = 512;
@@ -31,13 +29,7 @@ constexpr int kGemmLds = 2 * kBufBytes;      // 128 KiB
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gptr),       \
                                      (__attribute__((address_space(3))) void*)(lptr), 16, 0, 0)
 
-__device__ __forceinline__ uint32_t pack_bf16x2(float a, float b) {
-    typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
-    bf16x2 v = {static_cast<__bf16>(a), static_cast<__bf16>(b)};
-    return __builtin_bit_cast(uint32_t, v);
-}
-
-template <int EPI>
+template <int EPI, bool F16>
 __global__ __launch_bounds__(kGemmThreads) void gemm_bf16_kernel(const GemmParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
@@ -100,28 +92,28 @@ __global__ __launch_bounds__(kGemmThreads) void gemm_bf16_kernel(const GemmParam
         if (kt + 1 < nk) stage(kt + 1, (kt + 1) & 1);
         const char* base = smem + (kt & 1) * kBufBytes;
         // fragments of k-step s + 1 are read while the MFMAs of k-step s run
-        bf16x8 af[2][4], wf[2][2];
+        u16x8 af[2][4], wf[2][2];
 #pragma unroll
         for (int ms = 0; ms < 4; ++ms)
-            af[0][ms] = *reinterpret_cast<const bf16x8*>(base + a_row_off + ms * 4096 + coff[0]);
+            af[0][ms] = *reinterpret_cast<const u16x8*>(base + a_row_off + ms * 4096 + coff[0]);
 #pragma unroll
         for (int ns = 0; ns < 2; ++ns)
-            wf[0][ns] = *reinterpret_cast<const bf16x8*>(base + w_row_off + ns * 4096 + coff[0]);
+            wf[0][ns] = *reinterpret_cast<const u16x8*>(base + w_row_off + ns * 4096 + coff[0]);
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
             if (s + 1 < 4) {
 #pragma unroll
                 for (int ms = 0; ms < 4; ++ms)
-                    af[(s + 1) & 1][ms] = *reinterpret_cast<const bf16x8*>(base + a_row_off + ms * 4096 + coff[s + 1]);
+                    af[(s + 1) & 1][ms] = *reinterpret_cast<const u16x8*>(base + a_row_off + ms * 4096 + coff[s + 1]);
 #pragma unroll
                 for (int ns = 0; ns < 2; ++ns)
-                    wf[(s + 1) & 1][ns] = *reinterpret_cast<const bf16x8*>(base + w_row_off + ns * 4096 + coff[s + 1]);
+                    wf[(s + 1) & 1][ns] = *reinterpret_cast<const u16x8*>(base + w_row_off + ns * 4096 + coff[s + 1]);
             }
 #pragma unroll
             for (int ns = 0; ns < 2; ++ns)
 #pragma unroll
                 for (int ms = 0; ms < 4; ++ms)
-                    acc[ns][ms] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[s & 1][ns], af[s & 1][ms], acc[ns][ms], 0, 0, 0);
+                    acc[ns][ms] = mfma32<F16>(wf[s & 1][ns], af[s & 1][ms], acc[ns][ms]);
         }
     }
 
@@ -170,8 +162,8 @@ __global__ __launch_bounds__(kGemmThreads) void gemm_bf16_kernel(const GemmParam
 #pragma unroll
                         for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.0f);
                     }
-                    uint32_t lo0 = pack_bf16x2(v[0], v[1]), lo1 = pack_bf16x2(v[2], v[3]);
-                    uint32_t hi0 = pack_bf16x2(v[4], v[5]), hi1 = pack_bf16x2(v[6], v[7]);
+                    uint32_t lo0 = pack_elem2<F16>(v[0], v[1]), lo1 = pack_elem2<F16>(v[2], v[3]);
+                    uint32_t hi0 = pack_elem2<F16>(v[4], v[5]), hi1 = pack_elem2<F16>(v[6], v[7]);
                     // lanes 32..63 of lo swap with lanes 0..31 of hi: h = 0 ends with n 0..7, h = 1 with n 8..15
                     auto s0 = __builtin_amdgcn_permlane32_swap(lo0, hi0, false, false);
                     auto s1 = __builtin_amdgcn_permlane32_swap(lo1, hi1, false, false);
@@ -192,20 +184,31 @@ int32_t launch_gemm(asrfe_ctx* ctx, const GemmParams& pin, int epi, hipStream_t 
     p.n_tiles_n = p.N / BN;
     static bool attr_done = false;
     if (!attr_done) {
-        hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_kernel<EPI_BF16>), hipFuncAttributeMaxDynamicSharedMemorySize, kGemmLds);
-        hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_kernel<EPI_BF16_RELU>), hipFuncAttributeMaxDynamicSharedMemorySize, kGemmLds);
-        hipError_t e3 = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_kernel<EPI_F32_ADD>), hipFuncAttributeMaxDynamicSharedMemorySize, kGemmLds);
-        if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess)
-            return set_err(ctx, ASRFE_ERR_HIP, "gemm: cannot raise the dynamic LDS limit to 128 KiB");
+        const void* fns[6] = {reinterpret_cast<const void*>(gemm_bf16_kernel<EPI_BF16, false>),
+                              reinterpret_cast<const void*>(gemm_bf16_kernel<EPI_BF16_RELU, false>),
+                              reinterpret_cast<const void*>(gemm_bf16_kernel<EPI_F32_ADD, false>),
+                              reinterpret_cast<const void*>(gemm_bf16_kernel<EPI_BF16, true>),
+                              reinterpret_cast<const void*>(gemm_bf16_kernel<EPI_BF16_RELU, true>),
+                              reinterpret_cast<const void*>(gemm_bf16_kernel<EPI_F32_ADD, true>)};
+        for (const void* f : fns)
+            if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, kGemmLds) != hipSuccess)
+                return set_err(ctx, ASRFE_ERR_HIP, "gemm: cannot raise the dynamic LDS limit to 128 KiB");
         attr_done = true;
     }
     dim3 grid(p.n_tiles_m * p.n_tiles_n), block(kGemmThreads);
+    const bool f16 = ctx->cfg.enc_compute_dtype == ASRFE_DT_F16;
+#define LAUNCH_GEMM(E)                                                                        \
+    do {                                                                                      \
+        if (f16) hipLaunchKernelGGL((gemm_bf16_kernel<E, true>), grid, block, kGemmLds, s, p); \
+        else hipLaunchKernelGGL((gemm_bf16_kernel<E, false>), grid, block, kGemmLds, s, p);    \
+    } while (0)
     switch (epi) {
-        case EPI_BF16: hipLaunchKernelGGL(gemm_bf16_kernel<EPI_BF16>, grid, block, kGemmLds, s, p); break;
-        case EPI_BF16_RELU: hipLaunchKernelGGL(gemm_bf16_kernel<EPI_BF16_RELU>, grid, block, kGemmLds, s, p); break;
-        case EPI_F32_ADD: hipLaunchKernelGGL(gemm_bf16_kernel<EPI_F32_ADD>, grid, block, kGemmLds, s, p); break;
+        case EPI_BF16: LAUNCH_GEMM(EPI_BF16); break;
+        case EPI_BF16_RELU: LAUNCH_GEMM(EPI_BF16_RELU); break;
+        case EPI_F32_ADD: LAUNCH_GEMM(EPI_F32_ADD); break;
         default: return set_err(ctx, ASRFE_ERR_BAD_ARG, "gemm: bad epilogue");
     }
+#undef LAUNCH_GEMM
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) return set_err(ctx, ASRFE_ERR_HIP, std::string("gemm launch: ") + hipGetErrorString(e));
     return ASRFE_OK;

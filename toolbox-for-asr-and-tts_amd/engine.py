@@ -53,7 +53,7 @@ class AsrEngine:
         self.feats = torch.empty((batch, self.tp_max, c.lfr_m * c.n_mels), dtype=torch.float32, device=dev)
         self.feat_lens = torch.zeros((batch,), dtype=torch.int32, device=dev)
         self.out = torch.empty((batch, self.tp_max, c.enc_output_size), dtype=out_dtype, device=dev)
-        self.out_dtype = _lib.DT_BF16 if out_dtype == torch.bfloat16 else _lib.DT_F32
+        self.out_dtype = {torch.float32: _lib.DT_F32, torch.bfloat16: _lib.DT_BF16, torch.float16: _lib.DT_F16}[out_dtype]
         nbytes = self.encoder.workspace_bytes(batch, self.tp_max)
         self._ws = torch.empty((nbytes + 256,), dtype=torch.uint8, device=dev)
         self._ws_ptr = (self._ws.data_ptr() + 255) // 256 * 256
