@@ -80,6 +80,7 @@ def main():
     ap.add_argument("--cpu-clips", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-stages", action="store_true")
+    ap.add_argument("--streams", type=int, default=1, help="HIP streams (batch chunks) per GPU")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -101,7 +102,7 @@ def main():
     from toolbox_for_asr_and_tts_amd.synth import bench_pcm, encoder_state_dict
 
     sd = encoder_state_dict(num_blocks=50, seed=0)
-    eng = pkg.AsrEngine(batch=args.batch, max_samples=SAMPLES, state_dict=sd)
+    eng = pkg.AsrEngine(batch=args.batch, max_samples=SAMPLES, state_dict=sd, n_streams=args.streams)
     pcm = torch.from_numpy(bench_pcm(args.batch, SAMPLES, seed=1234 + rank)).to(dev)
     lens = torch.full((args.batch,), SAMPLES, dtype=torch.int32, device=dev)
 
@@ -148,6 +149,7 @@ def main():
                 "batch_per_gpu": args.batch,
                 "global_batch": world * args.batch,
                 "parallelism": f"utterance-sharded x{world}, no collective",
+                "streams_per_gpu": args.streams,
             },
             "output_finite": out_ok,
             "achieved_tflops_all": value * ALL_FLOP_PER_UTT / 1e12 / world,

@@ -96,6 +96,9 @@ SIGNATURES = {
     "asrfe_host_window": (C.c_int32, [C.POINTER(Config), C.POINTER(C.c_double)]),
     "asrfe_profile_begin": (C.c_int32, [C.c_void_p, C.c_int32]),
     "asrfe_profile_end": (C.c_int32, [C.c_void_p, C.POINTER(Profile)]),
+    "asrfe_debug_gemm": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32,
+                                     C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32,
+                                     C.c_int32, C.c_void_p]),
     "asrfe_last_error": (C.c_char_p, [C.c_void_p]),
     "asrfe_version": (C.c_char_p, []),
 }

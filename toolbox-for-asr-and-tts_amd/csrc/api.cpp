@@ -6,6 +6,7 @@
 #include <map>
 
 #include "common.h"
+#include "gemm.h"
 
 using namespace asrfe;
 
@@ -164,7 +165,8 @@ extern "C" int32_t asrfe_create(const asrfe_config* cfg, asrfe_ctx** out) {
     ctx->device = dev;
     ctx->cmvn_loaded = false;
     ctx->enc_loaded = false;
-    ctx->kin_pad = (cfg->enc_input_size + 63) / 64 * 64;
+    ctx->kin_pad = (cfg->enc_input_size + 127) / 128 * 128;
+    ctx->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     ctx->after_g = ctx->after_b = ctx->pe_inv = nullptr;
     std::memset(&ctx->tab, 0, sizeof(ctx->tab));
 
@@ -479,6 +481,20 @@ extern "C" int32_t asrfe_frontend(asrfe_ctx* ctx, const void* pcm, int32_t pcm_d
     p.lfr_lens = lens_out;
     ProfScope ps(ctx, PK_FRONTEND, static_cast<hipStream_t>(stream));
     return launch_fbank(ctx, p, pcm_dtype, true, out_dtype, static_cast<hipStream_t>(stream));
+}
+
+extern "C" int32_t asrfe_debug_gemm(asrfe_ctx* ctx, const void* a, int32_t lda, const void* w, int32_t ldw,
+                                    const float* bias, int32_t m, int32_t n, int32_t k, void* out, int32_t ldo,
+                                    const void* add16, const float* add32, int32_t epi, int32_t flags, void* stream) {
+    if (!ctx || !a || !w || !bias || !out) return set_err(ctx, ASRFE_ERR_BAD_ARG, "asrfe_debug_gemm: null argument");
+    GemmParams g{};
+    g.A = static_cast<const uint16_t*>(a); g.lda = lda;
+    g.W = static_cast<const uint16_t*>(w); g.ldw = ldw;
+    g.bias = bias; g.M = m; g.N = n; g.K = k; g.out = out; g.ldo = ldo;
+    g.add16 = static_cast<const uint16_t*>(add16); g.ld16 = ldo;
+    g.add32 = add32; g.ld32 = ldo;
+    g.flags = flags;
+    return launch_gemm(ctx, g, epi, static_cast<hipStream_t>(stream));
 }
 
 // ---- encoder entry points ----------------------------------------------------------------------

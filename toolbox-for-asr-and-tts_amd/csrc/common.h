@@ -71,7 +71,8 @@ struct asrfe_ctx {
     asrfe::FrontendTables tab;
     bool cmvn_loaded;
     bool enc_loaded;
-    int kin_pad;  // layer-0 K padded to a multiple of 64
+    int kin_pad;  // layer-0 K padded to a multiple of 128
+    int num_cus;  // compute units of the device (persistent kernels launch one workgroup per CU)
     std::vector<asrfe::LayerWeights> layers;
     float* after_g;
     float* after_b;

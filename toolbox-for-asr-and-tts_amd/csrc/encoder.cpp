@@ -2,7 +2,7 @@
 //
 // Per layer (d = 512):   h = LN1(x)                      ln kernel            bf16 [M][K]
 //                         qkv = h Wqkv^T + b              MFMA GEMM            bf16 [M][1536]
-//                         fsmn, V^T = FSMN(v), mask       fsmn kernel          f32 [M][512], bf16 [B][512][Tk]
+//                         fsmn, V^T = FSMN(v), mask       fsmn kernel          16-bit [M][512], 16-bit [B][512][Tk]
 //                         att = softmax(q k^T / sqrt(128)) v   attention kernel bf16 [M][512]
 //                         x = att Wo^T + b + fsmn (+ x)   MFMA GEMM            f32 [M][512]   (layer 0 has no residual)
 //                         h = LN2(x)                      ln kernel
@@ -34,7 +34,7 @@ struct Buffers {
     uint16_t* h;     // [M][max(kin_pad, 512)]
     uint16_t* qkv;   // [M][1536]
     uint16_t* vt;    // [B][512][Tk]
-    float* fsmn;     // [M][512]
+    uint16_t* fsmn;  // [M][512]
     uint16_t* att;   // [M][512]
     uint16_t* ffn;   // [M][ff]
     float* pe;       // [Tp][din]
@@ -51,7 +51,7 @@ Buffers carve(const asrfe_ctx* ctx, void* ws, int B, int Tp) {
     b.h = c.take<uint16_t>(M * hk);
     b.qkv = c.take<uint16_t>(M * 1536);
     b.vt = c.take<uint16_t>(static_cast<int64_t>(B) * 512 * Tk);
-    b.fsmn = c.take<float>(M * 512);
+    b.fsmn = c.take<uint16_t>(M * 512);
     b.att = c.take<uint16_t>(M * 512);
     b.ffn = c.take<uint16_t>(M * ctx->cfg.enc_linear_units);
     b.pe = c.take<float>(static_cast<int64_t>(Tp) * ctx->cfg.enc_input_size);
@@ -112,8 +112,8 @@ int32_t encoder_forward(asrfe_ctx* ctx, const float* feats, const int32_t* lens,
         g = GemmParams{};
         g.A = bf.att; g.lda = 512; g.W = L.w_out; g.ldw = 512; g.bias = L.b_out;
         g.M = M; g.N = 512; g.K = 512; g.out = bf.x; g.ldo = 512;
-        g.add1 = bf.fsmn; g.ld1 = 512;
-        g.add2 = li == 0 ? nullptr : bf.x; g.ld2 = 512;
+        g.add16 = bf.fsmn; g.ld16 = 512;
+        g.add32 = li == 0 ? nullptr : bf.x; g.ld32 = 512;
         { ProfScope ps(ctx, PK_GEMM_OUT, s); rc = launch_gemm(ctx, g, EPI_F32_ADD, s); }
         if (rc) return rc;
 
@@ -129,7 +129,7 @@ int32_t encoder_forward(asrfe_ctx* ctx, const float* feats, const int32_t* lens,
         g = GemmParams{};
         g.A = bf.ffn; g.lda = ff; g.W = L.w_ffn2; g.ldw = ff; g.bias = L.b_ffn2;
         g.M = M; g.N = 512; g.K = ff; g.out = bf.x; g.ldo = 512;
-        g.add1 = bf.x; g.ld1 = 512;
+        g.add32 = bf.x; g.ld32 = 512;
         { ProfScope ps(ctx, PK_GEMM_FFN2, s); rc = launch_gemm(ctx, g, EPI_F32_ADD, s); }
         if (rc) return rc;
     }

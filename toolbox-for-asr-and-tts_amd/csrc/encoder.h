@@ -34,6 +34,6 @@ int32_t launch_ln_final(asrfe_ctx* ctx, const float* x, const float* g, const fl
 
 // FSMN memory block on V (columns 1024..1535 of qkv) and the transposed V copy for attention
 int32_t launch_fsmn(asrfe_ctx* ctx, const uint16_t* qkv, int ld_qkv, const float* w /*[11][512]*/, const int32_t* lens,
-                    int B, int Tp, int Tk, float* fsmn /*[B*Tp][512]*/, uint16_t* vt /*[B][512][Tk]*/, hipStream_t s);
+                    int B, int Tp, int Tk, uint16_t* fsmn /*[B*Tp][512]*/, uint16_t* vt /*[B][512][Tk]*/, hipStream_t s);
 
 }  // namespace asrfe

@@ -157,7 +157,7 @@ constexpr int kFsmnLd = 65;
 template <bool F16>
 __global__ __launch_bounds__(256) void fsmn_kernel(const uint16_t* __restrict__ qkv, int ld_qkv,
                                                    const float* __restrict__ w, const int32_t* __restrict__ lens,
-                                                   int Tp, int Tk, float* __restrict__ fsmn,
+                                                   int Tp, int Tk, uint16_t* __restrict__ fsmn,
                                                    uint16_t* __restrict__ vt) {
     __shared__ float tile[kFsmnRows * kFsmnLd];
     __shared__ float wt[kFsmnTaps * 64];
@@ -195,11 +195,12 @@ __global__ __launch_bounds__(256) void fsmn_kernel(const uint16_t* __restrict__ 
             for (int j = 0; j < kFsmnTaps; ++j)
 #pragma unroll
                 for (int e = 0; e < 16; ++e) acc[e] = fmaf(wt[j * 64 + dq + e], tile[(tt + j) * kFsmnLd + dq + e], acc[e]);
-            float4* o = reinterpret_cast<float4*>(fsmn + (row0 + t) * 512 + d0 + dq);
+            uint4* o = reinterpret_cast<uint4*>(fsmn + (row0 + t) * 512 + d0 + dq);
+            uint32_t w8[8];
 #pragma unroll
-            for (int e = 0; e < 4; ++e)
-                o[e] = live ? make_float4(acc[4 * e], acc[4 * e + 1], acc[4 * e + 2], acc[4 * e + 3])
-                            : make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int e = 0; e < 8; ++e) w8[e] = live ? pack_elem2<F16>(acc[2 * e], acc[2 * e + 1]) : 0u;
+            o[0] = make_uint4(w8[0], w8[1], w8[2], w8[3]);
+            o[1] = make_uint4(w8[4], w8[5], w8[6], w8[7]);
         }
     }
     // transposed V: thread = (channel dd, 16 consecutive time steps); masked rows are already zero in the tile
@@ -216,7 +217,7 @@ __global__ __launch_bounds__(256) void fsmn_kernel(const uint16_t* __restrict__ 
 }
 
 int32_t launch_fsmn(asrfe_ctx* ctx, const uint16_t* qkv, int ld_qkv, const float* w, const int32_t* lens, int B, int Tp,
-                    int Tk, float* fsmn, uint16_t* vt, hipStream_t s) {
+                    int Tk, uint16_t* fsmn, uint16_t* vt, hipStream_t s) {
     if (B <= 0 || Tp <= 0) return ASRFE_OK;
     if (Tk % 64 != 0 || Tk < Tp) return set_err(ctx, ASRFE_ERR_SHAPE, "fsmn: Tk must be Tp rounded up to 64");
     if (ctx->cfg.enc_compute_dtype == ASRFE_DT_F16)

@@ -8,7 +8,7 @@ namespace asrfe {
 enum GemmEpilogue {
     EPI_BF16 = 0,       // out bf16 = acc + bias
     EPI_BF16_RELU = 1,  // out bf16 = relu(acc + bias)
-    EPI_F32_ADD = 2,    // out f32  = acc + bias (+ add1) (+ add2)
+    EPI_F32_ADD = 2,    // out f32  = acc + bias (+ add16) (+ add32)
 };
 
 struct GemmParams {
@@ -20,11 +20,12 @@ struct GemmParams {
     int M, N, K;
     void* out;          // [M][ldo]
     int ldo;
-    const float* add1;  // optional f32 [M][ld1]
-    int ld1;
-    const float* add2;  // optional f32 [M][ld2]
-    int ld2;
+    const uint16_t* add16;  // optional 16-bit [M][ld16] (same element type as A)
+    int ld16;
+    const float* add32;     // optional f32 [M][ld32]
+    int ld32;
     int n_tiles_m, n_tiles_n;  // filled by launch_gemm
+    int flags;                 // bit 0: skip the epilogue stores (timing experiments)
 };
 
 int32_t launch_gemm(asrfe_ctx* ctx, const GemmParams& p, int epi, hipStream_t s);

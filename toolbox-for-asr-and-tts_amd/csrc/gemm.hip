@@ -1,18 +1,30 @@
-// bf16 MFMA GEMM for the encoder linears on gfx950:  C[m][n] = sum_k A[m][k] * W[n][k]  (+ epilogue)
+// 16-bit MFMA GEMM for the encoder linears on gfx950:  C[m][n] = sum_k A[m][k] * W[n][k]  (+ epilogue)
 //
-//   A : activations, bf16 [M][lda], K contiguous;  W : torch Linear weight, bf16 [N][ldw], K contiguous.
-//   Tile 256 (m) x 256 (n) x 64 (k), 512 threads = 8 waves laid out 2 (m) x 4 (n); each wave owns a
-//   128 (m) x 64 (n) piece as 4 x 2 tiles of v_mfma_f32_32x32x16_bf16.
-//   Both operand tiles are staged global -> LDS with 16-byte LDS-DMA loads (no VGPR round trip) into
-//   two buffers, so the loads of K-tile t+1 fly while K-tile t is multiplied.  An LDS-DMA wave
-//   instruction writes 1 KiB linearly, so the bank swizzle is applied to the per-lane SOURCE address
-//   and undone on the fragment read: 16-byte chunk c of tile row r lives at chunk c ^ ((r >> 1) & 7),
-//   which makes every ds_read_b128 lane group hit 16 distinct 16-byte slots.
-//   The MFMA takes the W fragment as its A operand and the activation fragment as its B operand, so
-//   the accumulator has n in registers (4 consecutive n per register quad) and m on lanes: the
-//   epilogue then moves 16 bytes per lane (fp32 directly, bf16 after one v_permlane32_swap).
-//   Workgroup ids are remapped so that the 8 XCDs each walk a contiguous range of tiles (their L2s
-//   are private): the tiles that share an activation panel run on the same XCD at about the same time.
+//   A : activations [M][lda], W : torch Linear weight [N][ldw], both 16-bit (bf16 or fp16), K contiguous.
+//   Tile 256 (m) x 256 (n), K consumed 64 at a time; 512 threads = 8 waves laid out 2 (m) x 4 (n), each
+//   wave owning 128 (m) x 64 (n) as 4 x 2 tiles of v_mfma_f32_32x32x16.  The MFMA takes the W fragment as
+//   its A operand and the activation fragment as its B operand, so the accumulator has n in registers
+//   (4 consecutive n per register quad) and m on lanes: the epilogue moves 16 bytes per lane.
+//
+//   Staging.  Operands go global -> LDS by 16-byte LDS-DMA loads (no VGPR round trip).  Such a load writes
+//   1 KiB linearly per wave, so the bank swizzle is put on the per-lane SOURCE address and undone on the
+//   fragment read: 16-byte chunk c of tile row r lives at chunk c ^ ((r >> 1) & 7), which makes every
+//   ds_read_b128 lane group hit 16 distinct 16-byte slots.
+//
+//   Pipeline.  At 256 x 256 the kernel needs ~128 flop per byte pulled from L2, i.e. most of what a CU can
+//   pull, so the loads must never drain.  A K-tile is split in four 16 KiB half-tiles (A0/A1 = the first /
+//   second 64 rows of every wave's 128, B0/B1 = the first / second 32 columns of every wave's 64), LDS holds
+//   two K-tiles, and every K-tile is consumed in four phases of 8 MFMAs, one output quadrant each:
+//       even tile: (A0,B0) (A0,B1) (A1,B1) (A1,B0)      odd tile: (A0,B1) (A0,B0) (A1,B0) (A1,B1)
+//   so a half-tile is dead after a known phase and is refilled two phases later with the same half of the
+//   tile two K-tiles ahead: six half-tiles (96 KiB) are in flight in steady state.  Each phase ends with a
+//   counted "s_waitcnt vmcnt(10)" (all but the five youngest half-tiles of this wave have landed) and one
+//   s_barrier; no wait drains the queue before the last two K-tiles.  Fragment registers are refilled
+//   right after the MFMA that used them last, one phase before they are needed, so LDS latency is hidden
+//   without a second register set.
+//
+//   Workgroup ids are remapped so that each of the 8 XCDs (private L2s) walks a contiguous range of tiles:
+//   the tiles sharing an activation panel run on one XCD at about the same time.
 #include "common.h"
 #include "elem.h"
 #include "gemm.h"
@@ -21,116 +33,39 @@ namespace asrfe {
 
 constexpr int BM = 256, BN = 256, BK = 64;
 constexpr int kGemmThreads = 512;
-constexpr int kTileBytes = BM * BK * 2;      // 32 KiB per operand tile
-constexpr int kBufBytes = 2 * kTileBytes;    // A tile + W tile
-constexpr int kGemmLds = 2 * kBufBytes;      // 128 KiB
+constexpr int kHalfBytes = 128 * BK * 2;     // 16 KiB: one half-tile
+constexpr int kSlotBytes = 4 * kHalfBytes;   // A0 | A1 | B0 | B1
+constexpr int kGemmLds = 2 * kSlotBytes;     // 128 KiB
 
 #define GLDS16(gptr, lptr)                                                                         \
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gptr),       \
                                      (__attribute__((address_space(3))) void*)(lptr), 16, 0, 0)
 
+// End of a phase: this wave's loads for the next phase have landed and its LDS reads are done, then all
+// waves meet.  One asm statement, so nothing is scheduled between the wait and the barrier.
+#define PHASE_SYNC(steady)                                                                         \
+    do {                                                                                           \
+        if (steady) asm volatile("s_waitcnt vmcnt(10) lgkmcnt(0)\n\ts_barrier" ::: "memory");     \
+        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");             \
+    } while (0)
+
+// Epilogue of one output tile: lane owns row m, register quad g owns n = nb + 8 g + 4 h + {0..3}.
 template <int EPI, bool F16>
-__global__ __launch_bounds__(kGemmThreads) void gemm_bf16_kernel(const GemmParams p) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 2, wn = wave & 3;
-
-    // XCD-aware bijective remap of the workgroup id
-    const int nwg = gridDim.x, bid = blockIdx.x;
-    const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
-    const int logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-    const int tm = logical / p.n_tiles_n, tn = logical - tm * p.n_tiles_n;
-    const int m0 = tm * BM, n0 = tn * BN;
-
-    // staging: thread covers 16-byte chunk (tid & 7) of LDS row i * 64 + (tid >> 3), i = 0..3
-    const int srow = tid >> 3;
-    const int schunk = (tid & 7) ^ ((tid >> 4) & 7);  // source chunk for that LDS slot
-    const uint16_t* a_src[4];
-    const uint16_t* w_src[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        int ra = m0 + i * 64 + srow;
-        ra = ra < p.M ? ra : p.M - 1;
-        a_src[i] = p.A + static_cast<int64_t>(ra) * p.lda + schunk * 8;
-        w_src[i] = p.W + static_cast<int64_t>(n0 + i * 64 + srow) * p.ldw + schunk * 8;
-    }
-    const int wave_slot = wave * 1024;  // byte offset of this wave's 1 KiB piece inside an 8 KiB pass
-
-    auto stage = [&](int kt, int buf) {
-        char* ab = smem + buf * kBufBytes + wave_slot;
-        char* wb = ab + kTileBytes;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            GLDS16(a_src[i] + kt * BK, ab + i * 8192);
-            GLDS16(w_src[i] + kt * BK, wb + i * 8192);
-        }
-    };
-
-    // fragment read offsets
-    const int l31 = lane & 31, h = lane >> 5;
-    const int swz = (l31 >> 1) & 7;
-    int coff[4];
-#pragma unroll
-    for (int s = 0; s < 4; ++s) coff[s] = ((2 * s + h) ^ swz) << 4;
-    const int a_row_off = (wm * 128 + l31) * 128;               // + ms * 32 * 128
-    const int w_row_off = kTileBytes + (wn * 64 + l31) * 128;   // + ns * 32 * 128
-
-    f32x16 acc[2][4];
-#pragma unroll
-    for (int ns = 0; ns < 2; ++ns)
-#pragma unroll
-        for (int ms = 0; ms < 4; ++ms)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[ns][ms][e] = 0.0f;
-
-    const int nk = p.K / BK;
-    stage(0, 0);
-    for (int kt = 0; kt < nk; ++kt) {
-        __syncthreads();  // K-tile kt has landed (the barrier's fence drains the LDS-DMA loads); tile kt-1 is consumed
-        if (kt + 1 < nk) stage(kt + 1, (kt + 1) & 1);
-        const char* base = smem + (kt & 1) * kBufBytes;
-        // fragments of k-step s + 1 are read while the MFMAs of k-step s run
-        u16x8 af[2][4], wf[2][2];
-#pragma unroll
-        for (int ms = 0; ms < 4; ++ms)
-            af[0][ms] = *reinterpret_cast<const u16x8*>(base + a_row_off + ms * 4096 + coff[0]);
-#pragma unroll
-        for (int ns = 0; ns < 2; ++ns)
-            wf[0][ns] = *reinterpret_cast<const u16x8*>(base + w_row_off + ns * 4096 + coff[0]);
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            if (s + 1 < 4) {
-#pragma unroll
-                for (int ms = 0; ms < 4; ++ms)
-                    af[(s + 1) & 1][ms] = *reinterpret_cast<const u16x8*>(base + a_row_off + ms * 4096 + coff[s + 1]);
-#pragma unroll
-                for (int ns = 0; ns < 2; ++ns)
-                    wf[(s + 1) & 1][ns] = *reinterpret_cast<const u16x8*>(base + w_row_off + ns * 4096 + coff[s + 1]);
-            }
-#pragma unroll
-            for (int ns = 0; ns < 2; ++ns)
-#pragma unroll
-                for (int ms = 0; ms < 4; ++ms)
-                    acc[ns][ms] = mfma32<F16>(wf[s & 1][ns], af[s & 1][ms], acc[ns][ms]);
-        }
-    }
-
-    // ---- epilogue: lane owns row m, register quad g owns n = nb + 8 g + 4 h + {0..3} ----------
+__device__ __forceinline__ void gemm_epilogue(const GemmParams& p, const f32x16 (&acc)[2][4], int m0, int n0, int wm, int wn,
+                                              int l31, int h) {
 #pragma unroll
     for (int ns = 0; ns < 2; ++ns) {
         const int nb = n0 + wn * 64 + ns * 32;
         float bv[16];
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            const float4 t = *reinterpret_cast<const float4*>(p.bias + nb + 8 * g + 4 * h);
-            bv[4 * g] = t.x; bv[4 * g + 1] = t.y; bv[4 * g + 2] = t.z; bv[4 * g + 3] = t.w;
+            const float4 t4 = *reinterpret_cast<const float4*>(p.bias + nb + 8 * g + 4 * h);
+            bv[4 * g] = t4.x; bv[4 * g + 1] = t4.y; bv[4 * g + 2] = t4.z; bv[4 * g + 3] = t4.w;
         }
 #pragma unroll
         for (int ms = 0; ms < 4; ++ms) {
             const int m = m0 + wm * 128 + ms * 32 + l31;
-            const bool ok = m < p.M;
+            const bool ok = m < p.M && !(p.flags & 1);
             const f32x16 a = acc[ns][ms];
             if constexpr (EPI == EPI_F32_ADD) {
                 float* orow = reinterpret_cast<float*>(p.out) + static_cast<int64_t>(m) * p.ldo;
@@ -140,13 +75,16 @@ __global__ __launch_bounds__(kGemmThreads) void gemm_bf16_kernel(const GemmParam
                     float4 v = make_float4(a[4 * g] + bv[4 * g], a[4 * g + 1] + bv[4 * g + 1], a[4 * g + 2] + bv[4 * g + 2],
                                            a[4 * g + 3] + bv[4 * g + 3]);
                     if (ok) {
-                        if (p.add1) {
-                            const float4 t = *reinterpret_cast<const float4*>(p.add1 + static_cast<int64_t>(m) * p.ld1 + n);
-                            v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
+                        if (p.add16) {
+                            const uint2 t2 = *reinterpret_cast<const uint2*>(p.add16 + static_cast<int64_t>(m) * p.ld16 + n);
+                            float e0, e1, e2, e3;
+                            unpack_elem2<F16>(t2.x, e0, e1);
+                            unpack_elem2<F16>(t2.y, e2, e3);
+                            v.x += e0; v.y += e1; v.z += e2; v.w += e3;
                         }
-                        if (p.add2) {
-                            const float4 t = *reinterpret_cast<const float4*>(p.add2 + static_cast<int64_t>(m) * p.ld2 + n);
-                            v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
+                        if (p.add32) {
+                            const float4 t4 = *reinterpret_cast<const float4*>(p.add32 + static_cast<int64_t>(m) * p.ld32 + n);
+                            v.x += t4.x; v.y += t4.y; v.z += t4.z; v.w += t4.w;
                         }
                         *reinterpret_cast<float4*>(orow + n) = v;
                     }
@@ -175,11 +113,180 @@ __global__ __launch_bounds__(kGemmThreads) void gemm_bf16_kernel(const GemmParam
     }
 }
 
+template <int EPI, bool F16>
+__global__ __launch_bounds__(kGemmThreads) void gemm_bf16_kernel(const GemmParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+
+    // Persistent workgroups: the 8 XCDs (private L2s) each own a contiguous range of output tiles, and the
+    // workgroups of an XCD walk that range together, so tiles sharing an activation panel meet in one L2.
+    const int n_tiles = p.n_tiles_m * p.n_tiles_n;
+    const int nwg = gridDim.x, bid = blockIdx.x;
+    const int xcd = bid & 7;
+    const int wg_in_xcd = bid >> 3, wgs_of_xcd = (nwg - xcd + 7) >> 3;
+    const int tq = n_tiles >> 3, tr = n_tiles & 7;
+    const int tile_lo = xcd < tr ? xcd * (tq + 1) : tr * (tq + 1) + (xcd - tr) * tq;
+    const int tile_hi = tile_lo + tq + (xcd < tr ? 1 : 0);
+    const int first_tile = tile_lo + wg_in_xcd;
+    const int n_my = first_tile < tile_hi ? (tile_hi - first_tile + wgs_of_xcd - 1) / wgs_of_xcd : 0;
+    if (n_my == 0) return;
+    const int nk = p.K / BK;
+    const int n_kt = n_my * nk;  // K-tiles this workgroup consumes, over all its output tiles
+
+    // ---- staging: thread covers LDS slot (local row j * 64 + (tid >> 3), chunk tid & 7) of a half-tile
+    const int srow = tid >> 3;
+    const int schunk = (tid & 7) ^ ((tid >> 4) & 7);  // source chunk that belongs in that slot
+    const int wave_slot = wave * 1024;
+    const char* a_tile;
+    const char* w_tile;
+    uint32_t aoff[2][2], boff[2][2];  // [half][j] byte offsets from the tile base
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int cb = (2 * j + (tid >> 8)) * 64 + hf * 32 + (srow & 31);  // tile column behind this local row of weight half hf
+            boff[hf][j] = static_cast<uint32_t>(cb) * p.ldw * 2 + schunk * 16;
+        }
+    int st_tile = first_tile;  // output tile and K-tile the next staged K-tile belongs to
+    int st_kt = 0;
+    int st_left = n_kt;        // K-tiles still to stage
+    auto stage_set_tile = [&]() {
+        const int tm = st_tile / p.n_tiles_n, tn = st_tile - tm * p.n_tiles_n;
+        const int sm0 = tm * BM;
+        a_tile = reinterpret_cast<const char*>(p.A) + static_cast<int64_t>(sm0) * p.lda * 2;
+        w_tile = reinterpret_cast<const char*>(p.W) + static_cast<int64_t>(tn * BN) * p.ldw * 2;
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                int ra_ = j * 128 + hf * 64 + srow;  // tile row behind this local row of activation half hf
+                ra_ = (sm0 + ra_ < p.M) ? ra_ : (p.M - 1 - sm0);
+                aoff[hf][j] = static_cast<uint32_t>(ra_) * p.lda * 2 + schunk * 16;
+            }
+    };
+    // after the four halves of a K-tile have been issued
+    auto stage_advance = [&]() {
+        --st_left;
+        if (++st_kt == nk) {
+            st_kt = 0;
+            st_tile += wgs_of_xcd;
+            if (st_left > 0) stage_set_tile();
+        }
+    };
+    // half: 0 A0, 1 A1, 2 B0, 3 B1
+    auto stage = [&](int half, int slot) {
+        char* dst = smem + slot * kSlotBytes + half * kHalfBytes + wave_slot;
+        const int kb = st_kt * (BK * 2);
+        if (half < 2) {
+            GLDS16(a_tile + aoff[half][0] + kb, dst);
+            GLDS16(a_tile + aoff[half][1] + kb, dst + 8192);
+        } else {
+            GLDS16(w_tile + boff[half - 2][0] + kb, dst);
+            GLDS16(w_tile + boff[half - 2][1] + kb, dst + 8192);
+        }
+    };
+
+    // ---- fragment read offsets
+    const int l31 = lane & 31, h = lane >> 5;
+    const int swz = (l31 >> 1) & 7;
+    int coff[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) coff[s] = ((2 * s + h) ^ swz) << 4;
+    const int a_row_off = (wm * 64 + l31) * 128;                   // + a * kHalfBytes + ms * 4096
+    const int b_row_off = 2 * kHalfBytes + (wn * 32 + l31) * 128;  // + b * kHalfBytes
+
+    u16x8 ra[2][4];    // activation fragments [ms][s] of the current A half
+    u16x8 rb[2][4];    // weight fragments [b][s]: rb[0] always holds B0, rb[1] always holds B1
+    f32x16 acc[2][4];  // [b][a * 2 + ms]
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int ms = 0; ms < 4; ++ms)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[b][ms][e] = 0.0f;
+
+    auto read_a = [&](int a, int slot, int ms, int s) {
+        ra[ms][s] = *reinterpret_cast<const u16x8*>(smem + slot * kSlotBytes + a * kHalfBytes + a_row_off + ms * 4096 + coff[s]);
+    };
+    auto read_b = [&](int b, int slot) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+            rb[b][s] = *reinterpret_cast<const u16x8*>(smem + slot * kSlotBytes + b * kHalfBytes + b_row_off + coff[s]);
+    };
+
+    // One phase: 8 MFMAs of quadrant (A_, B_).  ROLL_A >= 0: refill ra with half ROLL_A of ROLL_SLOT as it is
+    // consumed.  FREE_B >= 0: load rb[FREE_B] (idle in this phase) from FREE_SLOT.  STAGE: issue that half of
+    // the K-tile two ahead (if it exists).
+#define PHASE(A_, B_, STAGE_HALF, STAGE_SLOT, FREE_B, FREE_SLOT, ROLL_A, ROLL_SLOT, SYNC, STEADY)            \
+    do {                                                                                                    \
+        if ((STEADY) && !no_stage) stage(STAGE_HALF, STAGE_SLOT);                                           \
+        if (FREE_B >= 0 && !no_read) read_b(FREE_B < 0 ? 0 : FREE_B, FREE_SLOT);                            \
+        _Pragma("unroll") for (int s = 0; s < 4; ++s) {                                                     \
+            _Pragma("unroll") for (int ms = 0; ms < 2; ++ms) {                                              \
+                acc[B_][(A_) * 2 + ms] = mfma32<F16>(rb[B_][s], ra[ms][s], acc[B_][(A_) * 2 + ms]);         \
+                if (ROLL_A >= 0 && !no_read) read_a(ROLL_A < 0 ? 0 : ROLL_A, ROLL_SLOT, ms, s);             \
+            }                                                                                               \
+        }                                                                                                   \
+        if ((SYNC) && !no_sync) PHASE_SYNC(STEADY);                                                         \
+    } while (0)
+
+    // timing experiments only (results are wrong when any of these is set)
+    const bool no_stage = p.flags & 2, no_sync = p.flags & 4, no_read = p.flags & 8;
+
+    // ---- prologue: the first two K-tiles in flight, then the first fragments
+    stage_set_tile();
+    stage(0, 0); stage(2, 0); stage(3, 0); stage(1, 0);
+    stage_advance();
+    stage(0, 1); stage(3, 1); stage(2, 1); stage(1, 1);
+    stage_advance();
+    PHASE_SYNC(true);  // A0, B0, B1 of K-tile 0 landed (five half-tiles may still fly)
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int ms = 0; ms < 2; ++ms) read_a(0, 0, ms, s);
+    read_b(0, 0);
+
+    int cur_tile = first_tile;
+    int kt_in_tile = 0;
+    for (int g = 0; g < n_kt; g += 2) {
+        const bool st0 = st_left > 0;  // K-tile g + 2 exists: its halves are issued during K-tile g
+        //     use    stage(half, slot)   free read    rolling A     sync
+        PHASE(0, 0,   0, 0,               1, 0,        -1, 0,        true, st0);
+        PHASE(0, 1,   2, 0,              -1, 0,         1, 0,        false, st0);
+        PHASE(1, 1,   3, 0,              -1, 0,        -1, 0,        true, st0);
+        PHASE(1, 0,   1, 0,               1, 1,         0, 1,        true, st0);
+        if (st0) stage_advance();
+        const bool st1 = st_left > 0;  // K-tile g + 3
+        PHASE(0, 1,   0, 1,               0, 1,        -1, 0,        true, st1);
+        PHASE(0, 0,   3, 1,              -1, 0,         1, 1,        false, st1);
+        PHASE(1, 0,   2, 1,              -1, 0,        -1, 0,        true, st1);
+        PHASE(1, 1,   1, 1,               0, 0,         0, 0,        true, st1);
+        if (st1) stage_advance();
+        kt_in_tile += 2;
+        if (kt_in_tile == nk) {  // this output tile is complete: store it while the next tile's loads fly
+            const int tm = cur_tile / p.n_tiles_n, tn = cur_tile - tm * p.n_tiles_n;
+            gemm_epilogue<EPI, F16>(p, acc, tm * BM, tn * BN, wm, wn, l31, h);
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int ms = 0; ms < 4; ++ms)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) acc[b][ms][e] = 0.0f;
+            kt_in_tile = 0;
+            cur_tile += wgs_of_xcd;
+        }
+    }
+#undef PHASE
+}
+
 int32_t launch_gemm(asrfe_ctx* ctx, const GemmParams& pin, int epi, hipStream_t s) {
     GemmParams p = pin;
     if (p.M <= 0) return ASRFE_OK;
-    if (p.N % BN != 0 || p.K % BK != 0 || p.K <= 0 || p.lda % 8 != 0 || p.ldw % 8 != 0 || p.ldo % 8 != 0)
-        return set_err(ctx, ASRFE_ERR_SHAPE, "gemm: N must be a multiple of 256, K of 64, leading dims of 8");
+    if (p.N % BN != 0 || p.K % (2 * BK) != 0 || p.K <= 0 || p.lda % 8 != 0 || p.ldw % 8 != 0 || p.ldo % 8 != 0)
+        return set_err(ctx, ASRFE_ERR_SHAPE, "gemm: N must be a multiple of 256, K of 128, leading dims of 8");
     p.n_tiles_m = (p.M + BM - 1) / BM;
     p.n_tiles_n = p.N / BN;
     static bool attr_done = false;
@@ -195,7 +302,8 @@ int32_t launch_gemm(asrfe_ctx* ctx, const GemmParams& pin, int epi, hipStream_t 
                 return set_err(ctx, ASRFE_ERR_HIP, "gemm: cannot raise the dynamic LDS limit to 128 KiB");
         attr_done = true;
     }
-    dim3 grid(p.n_tiles_m * p.n_tiles_n), block(kGemmThreads);
+    const int n_tiles = p.n_tiles_m * p.n_tiles_n;
+    dim3 grid(n_tiles < ctx->num_cus ? n_tiles : ctx->num_cus), block(kGemmThreads);
     const bool f16 = ctx->cfg.enc_compute_dtype == ASRFE_DT_F16;
 #define LAUNCH_GEMM(E)                                                                        \
     do {                                                                                      \

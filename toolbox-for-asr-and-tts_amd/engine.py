@@ -31,8 +31,12 @@ def shard_range(n_items: int, rank: int, world_size: int):
 
 
 class AsrEngine:
+    """``n_streams`` > 1 splits the batch into that many contiguous chunks, each with its own buffers and HIP
+    stream: the kernels of different chunks overlap on the GPU (one chunk's memory-bound phases run beside
+    another's MFMA phases), which a single in-order stream cannot do.  Results are identical to n_streams = 1."""
+
     def __init__(self, batch: int, max_samples: int, cfg: _lib.Config | None = None, device=None,
-                 out_dtype=torch.float32, cmvn: tuple | None = None, state_dict=None):
+                 out_dtype=torch.float32, cmvn: tuple | None = None, state_dict=None, n_streams: int = 1):
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
         with torch.cuda.device(self.device):
             self.ctx = _lib.Context(cfg)
@@ -54,13 +58,18 @@ class AsrEngine:
         self.feat_lens = torch.zeros((batch,), dtype=torch.int32, device=dev)
         self.out = torch.empty((batch, self.tp_max, c.enc_output_size), dtype=out_dtype, device=dev)
         self.out_dtype = {torch.float32: _lib.DT_F32, torch.bfloat16: _lib.DT_BF16, torch.float16: _lib.DT_F16}[out_dtype]
-        nbytes = self.encoder.workspace_bytes(batch, self.tp_max)
-        self._ws = torch.empty((nbytes + 256,), dtype=torch.uint8, device=dev)
-        self._ws_ptr = (self._ws.data_ptr() + 255) // 256 * 256
-        self._ws_bytes = nbytes
+        n_streams = max(1, min(int(n_streams), batch))
+        self.chunks = [shard_range(batch, i, n_streams) for i in range(n_streams)]
+        self._ws = []
+        for lo, hi in self.chunks:
+            nbytes = self.encoder.workspace_bytes(hi - lo, self.tp_max)
+            buf = torch.empty((nbytes + 256,), dtype=torch.uint8, device=dev)
+            self._ws.append((buf, (buf.data_ptr() + 255) // 256 * 256, nbytes))
+        with torch.cuda.device(dev):
+            self._streams = [torch.cuda.Stream(device=dev) for _ in range(n_streams)] if n_streams > 1 else [None]
+            self._done = [torch.cuda.Event() for _ in range(n_streams)]
 
-    def run_frontend(self, pcm: torch.Tensor, pcm_lens: torch.Tensor):
-        """pcm [batch, >= max len] int16/float32 and pcm_lens [batch] int32, both on this device."""
+    def _check_pcm(self, pcm: torch.Tensor, pcm_lens: torch.Tensor):
         if pcm.device != self.device or pcm_lens.device != self.device or pcm_lens.dtype != torch.int32:
             raise ValueError("AsrEngine: pcm and pcm_lens (int32) must live on the engine's device")
         if pcm.dim() != 2 or pcm.shape[0] != self.batch or pcm.shape[1] > self.max_samples or pcm.stride(1) != 1:
@@ -68,22 +77,52 @@ class AsrEngine:
         dt = {torch.int16: _lib.PCM_I16, torch.float32: _lib.PCM_F32}.get(pcm.dtype)
         if dt is None:
             raise ValueError("AsrEngine: PCM dtype must be int16 or float32")
-        stream = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
-        self.ctx.check(self.ctx.lib.asrfe_frontend(self.ctx.handle, pcm.data_ptr(), dt, pcm.stride(0),
-                                                   pcm_lens.data_ptr(), self.batch, self.tp_max,
-                                                   self.feats.data_ptr(), _lib.DT_F32, self.feat_lens.data_ptr(),
-                                                   stream))
+        return dt
+
+    def _frontend_chunk(self, pcm, pcm_lens, dt, lo, hi, stream):
+        self.ctx.check(self.ctx.lib.asrfe_frontend(
+            self.ctx.handle, pcm.data_ptr() + lo * pcm.stride(0) * pcm.element_size(), dt, pcm.stride(0),
+            pcm_lens.data_ptr() + 4 * lo, hi - lo, self.tp_max, self.feats[lo:hi].data_ptr(), _lib.DT_F32,
+            self.feat_lens.data_ptr() + 4 * lo, stream))
+
+    def _encoder_chunk(self, i, lo, hi, stream):
+        _, ptr, nbytes = self._ws[i]
+        self.ctx.check(self.ctx.lib.asrfe_encoder_forward(
+            self.ctx.handle, self.feats[lo:hi].data_ptr(), self.feat_lens.data_ptr() + 4 * lo, hi - lo, self.tp_max,
+            self.out[lo:hi].data_ptr(), self.out_dtype, ptr, nbytes, stream))
+
+    def _run(self, pcm, pcm_lens, frontend: bool, encoder: bool):
+        dt = self._check_pcm(pcm, pcm_lens) if frontend else None
+        cur = torch.cuda.current_stream(self.device)
+        if len(self.chunks) == 1:
+            st = C.c_void_p(cur.cuda_stream)
+            if frontend:
+                self._frontend_chunk(pcm, pcm_lens, dt, 0, self.batch, st)
+            if encoder:
+                self._encoder_chunk(0, 0, self.batch, st)
+            return
+        for i, (lo, hi) in enumerate(self.chunks):
+            s = self._streams[i]
+            s.wait_stream(cur)  # inputs produced on the caller's stream are ready
+            st = C.c_void_p(s.cuda_stream)
+            if frontend:
+                self._frontend_chunk(pcm, pcm_lens, dt, lo, hi, st)
+            if encoder:
+                self._encoder_chunk(i, lo, hi, st)
+            self._done[i].record(s)
+        for ev in self._done:
+            cur.wait_event(ev)
+
+    def run_frontend(self, pcm: torch.Tensor, pcm_lens: torch.Tensor):
+        """pcm [batch, >= max len] int16/float32 and pcm_lens [batch] int32, both on this device."""
+        self._run(pcm, pcm_lens, True, False)
         return self.feats, self.feat_lens
 
     def run_encoder(self):
-        stream = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
-        self.ctx.check(self.ctx.lib.asrfe_encoder_forward(self.ctx.handle, self.feats.data_ptr(),
-                                                          self.feat_lens.data_ptr(), self.batch, self.tp_max,
-                                                          self.out.data_ptr(), self.out_dtype, self._ws_ptr,
-                                                          self._ws_bytes, stream))
+        self._run(None, None, False, True)
         return self.out, self.feat_lens
 
     def run(self, pcm: torch.Tensor, pcm_lens: torch.Tensor):
         """One step of the hot path; returns (encoder_out [batch, T', 512], out_lens [batch]) views of engine buffers."""
-        self.run_frontend(pcm, pcm_lens)
-        return self.run_encoder()
+        self._run(pcm, pcm_lens, True, True)
+        return self.out, self.feat_lens
