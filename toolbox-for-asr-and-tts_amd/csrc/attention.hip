@@ -28,21 +28,64 @@ constexpr int kVTileBytes = 128 * kVRow;
 
 template <bool F16>
 __global__ __launch_bounds__(kAttnThreads) void attn_kernel(const AttnParams p) {
-    __shared__ __attribute__((aligned(16))) char smem[kKTileBytes + kVTileBytes];
-    char* ks = smem;
-    char* vs = smem + kKTileBytes;
-
+    // two K/V buffers: tile kt + 1 is fetched while tile kt is multiplied
+    __shared__ __attribute__((aligned(16))) char smem[2 * (kKTileBytes + kVTileBytes)];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, h = lane >> 5;
-    const int b = blockIdx.z, head = blockIdx.y;
+    // Workgroups are dealt round-robin over the 8 XCDs (private L2s).  Remap the linear id so that each XCD
+    // gets a contiguous range of (utterance, head, query tile) triples, query tile fastest: the workgroups that
+    // share one head's K and V then run on the same XCD at about the same time and hit in its L2.
+    const int nwg = gridDim.x, bid = blockIdx.x;
+    const int xcd = bid & 7, xq = nwg >> 3, xr = nwg & 7;
+    const int logical = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (bid >> 3);
+    const int qtile = logical % p.n_qtiles;
+    const int head = (logical / p.n_qtiles) & 3;
+    const int b = logical / (p.n_qtiles * 4);
     int len = p.lens[b];
     len = len < 0 ? 0 : (len > p.Tp ? p.Tp : len);
-    const int q0 = blockIdx.x * 128 + wave * 32;
+    const int q0 = qtile * 128 + wave * 32;
     const int64_t row0 = static_cast<int64_t>(b) * p.Tp;
     const int n_kt = (len + 63) >> 6;
 
+    // staging addresses
+    const int k_row = tid >> 4;                                   // + 16 i
+    const int k_chunk = (tid & 15) ^ ((tid >> 4) & 15);           // source chunk for LDS slot (row, tid & 15)
+    const int v_row = tid >> 3;                                   // + 32 i
+    const int v_chunk = tid & 7;
+    const uint16_t* vbase = p.vt + (static_cast<int64_t>(b) * 512 + head * 128) * p.Tk;
+    const uint16_t* kbase = p.qkv + 512 + head * 128 + k_chunk * 8;
+
+    auto k_issue = [&](int kt, int buf) {
+        char* ks = smem + buf * (kKTileBytes + kVTileBytes);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            int key = kt * 64 + i * 16 + k_row;
+            key = key < p.Tp ? key : p.Tp - 1;
+            GLDS16(kbase + (row0 + key) * p.ld_qkv, ks + i * 4096 + wave * 1024);
+        }
+    };
+    uint4 vreg[4];
+    auto v_load = [&](int kt) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            vreg[i] = *reinterpret_cast<const uint4*>(vbase + static_cast<int64_t>(i * 32 + v_row) * p.Tk + kt * 64 + v_chunk * 8);
+    };
+    auto v_store = [&](int buf) {
+        char* vs = smem + buf * (kKTileBytes + kVTileBytes) + kKTileBytes;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            uint2* dst = reinterpret_cast<uint2*>(vs + (i * 32 + v_row) * kVRow + v_chunk * 16);
+            dst[0] = make_uint2(vreg[i].x, vreg[i].y);
+            dst[1] = make_uint2(vreg[i].z, vreg[i].w);
+        }
+    };
+
+    if (n_kt > 0) {
+        k_issue(0, 0);
+        v_load(0);
+    }
     // Q fragments: lane holds Q[q0 + l31][16 s + 8 h .. +8), s = 0..7
     u16x8 qf[8];
     {
@@ -52,6 +95,7 @@ __global__ __launch_bounds__(kAttnThreads) void attn_kernel(const AttnParams p) 
 #pragma unroll
         for (int s = 0; s < 8; ++s) qf[s] = *reinterpret_cast<const u16x8*>(qp + 16 * s);
     }
+    if (n_kt > 0) v_store(0);
 
     f32x16 oacc[4];
 #pragma unroll
@@ -61,31 +105,18 @@ __global__ __launch_bounds__(kAttnThreads) void attn_kernel(const AttnParams p) 
     float m_run = -INFINITY, l_run = 0.0f;
     const float c = p.scale_log2;
 
-    // staging addresses
-    const int k_row = tid >> 4;                                   // + 16 i
-    const int k_chunk = (tid & 15) ^ ((tid >> 4) & 15);           // source chunk for LDS slot (row, tid & 15)
-    const int v_row = tid >> 3;                                   // + 32 i
-    const int v_chunk = tid & 7;
-    const uint16_t* vbase = p.vt + (static_cast<int64_t>(b) * 512 + head * 128) * p.Tk;
-
     for (int kt = 0; kt < n_kt; ++kt) {
-        __syncthreads();  // previous tile fully consumed
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            int key = kt * 64 + i * 16 + k_row;
-            key = key < p.Tp ? key : p.Tp - 1;
-            GLDS16(p.qkv + (row0 + key) * p.ld_qkv + 512 + head * 128 + k_chunk * 8, ks + i * 4096 + wave * 1024);
+        const int cur = kt & 1;
+        // tile kt is complete in LDS (the barrier's fence drains this thread's LDS-DMA loads and LDS writes) and
+        // every wave is done with tile kt - 1, whose buffer is refilled below
+        __syncthreads();
+        const bool more = kt + 1 < n_kt;
+        if (more) {
+            k_issue(kt + 1, cur ^ 1);
+            v_load(kt + 1);
         }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int d = i * 32 + v_row;
-            const uint2* src = reinterpret_cast<const uint2*>(vbase + static_cast<int64_t>(d) * p.Tk + kt * 64 + v_chunk * 8);
-            const uint2 a = src[0], bq = src[1];
-            uint2* dst = reinterpret_cast<uint2*>(vs + d * kVRow + v_chunk * 16);
-            dst[0] = a;
-            dst[1] = bq;
-        }
-        __syncthreads();  // drains the LDS-DMA loads and publishes the V writes
+        const char* ks = smem + cur * (kKTileBytes + kVTileBytes);
+        const char* vs = ks + kKTileBytes;
 
         // ---- S^T = K Q^T : two 32-key sub-tiles ---------------------------------------------
         f32x16 sacc[2];
@@ -118,6 +149,7 @@ __global__ __launch_bounds__(kAttnThreads) void attn_kernel(const AttnParams p) 
         const float m_new = fmaxf(m_run, rmax);  // finite: every tile holds at least one valid key
         const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);
         const float mc = m_new * c;
+        const bool grew = m_new != m_run;
         m_run = m_new;
         float psum = 0.0f;
         u16x8 pf[2][2];
@@ -132,10 +164,12 @@ __global__ __launch_bounds__(kAttnThreads) void attn_kernel(const AttnParams p) 
                     pf[kk][s2][j] = to_elem<F16>(pv);
                 }
         l_run = l_run * alpha + psum;
+        if (__any(grew)) {  // no lane's maximum moved: alpha is exactly 1 everywhere, skip the rescale
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt)
+            for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) oacc[mt][e] *= alpha;
+                for (int e = 0; e < 16; ++e) oacc[mt][e] *= alpha;
+        }
 
         // ---- O^T += V^T P^T ----------------------------------------------------------------------
 #pragma unroll
@@ -152,14 +186,14 @@ __global__ __launch_bounds__(kAttnThreads) void attn_kernel(const AttnParams p) 
                     oacc[mt] = mfma32<F16>(vf, pf[kk][s2], oacc[mt]);
                 }
         }
+        if (more) v_store(cur ^ 1);
     }
 
-    // ---- normalise and store: lane owns query row q0 + l31, register quad g owns d = 8 g + 4 h + {0..3} ----
+    // ---- normalise; each wave routes its 32 x 128 tile through LDS so that 16 lanes store one full 256-byte row ----
     const float l_tot = l_run + __shfl_xor(l_run, 32);
     const float inv = l_tot > 0.0f ? 1.0f / l_tot : 0.0f;
-    const int qr = q0 + l31;
-    const bool ok = qr < p.Tp;
-    uint16_t* orow = p.out + (row0 + (ok ? qr : 0)) * p.ld_out + head * 128;
+    __syncthreads();  // all waves are done with the K/V buffers
+    char* es = smem + wave * 8192;
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
@@ -170,16 +204,29 @@ __global__ __launch_bounds__(kAttnThreads) void attn_kernel(const AttnParams p) 
             uint32_t hi1 = pack_elem2<F16>(oacc[mt][8 * gp + 6] * inv, oacc[mt][8 * gp + 7] * inv);
             auto s0 = __builtin_amdgcn_permlane32_swap(lo0, hi0, false, false);
             auto s1 = __builtin_amdgcn_permlane32_swap(lo1, hi1, false, false);
-            if (ok) *reinterpret_cast<uint4*>(orow + mt * 32 + 16 * gp + 8 * h) = make_uint4(s0[0], s1[0], s0[1], s1[1]);
+            const int chunk = 4 * mt + 2 * gp + h;  // 16-byte chunk of the 256-byte row: d = 8 chunk .. +8
+            *reinterpret_cast<uint4*>(es + l31 * 256 + ((chunk ^ (l31 & 15)) << 4)) = make_uint4(s0[0], s1[0], s0[1], s1[1]);
         }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int r = i * 4 + (lane >> 4), cch = lane & 15;
+        const uint4 v = *reinterpret_cast<const uint4*>(es + r * 256 + ((cch ^ (r & 15)) << 4));
+        const int qr = q0 + r;
+        if (qr < p.Tp) *reinterpret_cast<uint4*>(p.out + (row0 + qr) * p.ld_out + head * 128 + cch * 8) = v;
+    }
 }
 
 int32_t launch_attention(asrfe_ctx* ctx, const AttnParams& p, hipStream_t s) {
     if (p.B <= 0 || p.Tp <= 0) return ASRFE_OK;
     if (p.Tk % 64 != 0 || p.Tk < p.Tp) return set_err(ctx, ASRFE_ERR_SHAPE, "attention: Tk must be Tp rounded up to 64");
-    dim3 grid((p.Tp + 127) / 128, 4, p.B);
-    if (ctx->cfg.enc_compute_dtype == ASRFE_DT_F16) hipLaunchKernelGGL(attn_kernel<true>, grid, dim3(kAttnThreads), 0, s, p);
-    else hipLaunchKernelGGL(attn_kernel<false>, grid, dim3(kAttnThreads), 0, s, p);
+    AttnParams q = p;
+    q.n_qtiles = (p.Tp + 127) / 128;
+    dim3 grid(q.n_qtiles * 4 * p.B);
+    if (ctx->cfg.enc_compute_dtype == ASRFE_DT_F16) hipLaunchKernelGGL(attn_kernel<true>, grid, dim3(kAttnThreads), 0, s, q);
+    else hipLaunchKernelGGL(attn_kernel<false>, grid, dim3(kAttnThreads), 0, s, q);
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) return set_err(ctx, ASRFE_ERR_HIP, std::string("attention launch: ") + hipGetErrorString(e));
     return ASRFE_OK;

@@ -13,6 +13,7 @@ struct AttnParams {
     uint16_t* out;        // bf16 [B*Tp][ld_out]
     int ld_out;
     int B, Tp, Tk;
+    int n_qtiles;         // filled by launch_attention
     float scale_log2;     // log2(e) / sqrt(d_k)
 };
 int32_t launch_attention(asrfe_ctx* ctx, const AttnParams& p, hipStream_t s);

@@ -35,7 +35,8 @@ constexpr int BM = 256, BN = 256, BK = 64;
 constexpr int kGemmThreads = 512;
 constexpr int kHalfBytes = 128 * BK * 2;     // 16 KiB: one half-tile
 constexpr int kSlotBytes = 4 * kHalfBytes;   // A0 | A1 | B0 | B1
-constexpr int kGemmLds = 2 * kSlotBytes;     // 128 KiB
+constexpr int kRingBytes = 2 * kSlotBytes;   // 128 KiB
+constexpr int kGemmLds = kRingBytes + 8 * 4096;  // + one 4 KiB epilogue slab per wave = 160 KiB
 
 #define GLDS16(gptr, lptr)                                                                         \
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gptr),       \
@@ -49,32 +50,58 @@ constexpr int kGemmLds = 2 * kSlotBytes;     // 128 KiB
         else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");             \
     } while (0)
 
-// Epilogue of one output tile: lane owns row m, register quad g owns n = nb + 8 g + 4 h + {0..3}.
+// 16-byte global store with a selectable cache policy: 0 plain, 1 non-temporal, 2 write-through (sc1)
+__device__ __forceinline__ void store16(void* ptr, uint4 v, int policy) {
+    typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+    const u32x4 d = {v.x, v.y, v.z, v.w};
+    if (policy == 1) {
+        __builtin_nontemporal_store(d, reinterpret_cast<u32x4*>(ptr));
+    } else if (policy == 2) {
+        asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(ptr), "v"(d) : "memory");
+    } else {
+        *reinterpret_cast<u32x4*>(ptr) = d;
+    }
+}
+
+__device__ __forceinline__ void wave_lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// Epilogue of one output tile (the bias is already in the accumulator: it is its initial value).  In the accumulator a lane owns row m and register quad g owns the columns
+// nb + 8 g + 4 h + {0..3}, so a direct store would scatter 32-byte pieces over 32 rows.  Instead every
+// 32-row slab goes through a 4 KiB wave-private LDS tile (128-byte rows, 16-byte chunk c of row r kept at
+// chunk c ^ (r & 7): conflict-free both ways) and comes back with 8 consecutive lanes holding one full
+// 128-byte line, so each global access moves whole lines.  Only wave-level ordering is needed.
 template <int EPI, bool F16>
 __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, const f32x16 (&acc)[2][4], int m0, int n0, int wm, int wn,
-                                              int l31, int h) {
+                                              int lane, char* es) {
+    const int l31 = lane & 31, h = lane >> 5;
+    const int wr_row = l31 * 128, wr_sw = l31 & 7;   // this lane's row in the slab when writing
+    const int rd_row = lane >> 3, rd_c = lane & 7;   // row (+ 8 i) and chunk when reading back
+    const bool live = !(p.flags & 1);
+    const int policy = (p.flags >> 4) & 3;
+    if constexpr (EPI == EPI_F32_ADD) {
 #pragma unroll
-    for (int ns = 0; ns < 2; ++ns) {
-        const int nb = n0 + wn * 64 + ns * 32;
-        float bv[16];
+        for (int ns = 0; ns < 2; ++ns) {
+            const int nb = n0 + wn * 64 + ns * 32;
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const float4 t4 = *reinterpret_cast<const float4*>(p.bias + nb + 8 * g + 4 * h);
-            bv[4 * g] = t4.x; bv[4 * g + 1] = t4.y; bv[4 * g + 2] = t4.z; bv[4 * g + 3] = t4.w;
-        }
+            for (int ms = 0; ms < 4; ++ms) {
+                const f32x16 a = acc[ns][ms];
 #pragma unroll
-        for (int ms = 0; ms < 4; ++ms) {
-            const int m = m0 + wm * 128 + ms * 32 + l31;
-            const bool ok = m < p.M && !(p.flags & 1);
-            const f32x16 a = acc[ns][ms];
-            if constexpr (EPI == EPI_F32_ADD) {
-                float* orow = reinterpret_cast<float*>(p.out) + static_cast<int64_t>(m) * p.ldo;
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const int n = nb + 8 * g + 4 * h;
-                    float4 v = make_float4(a[4 * g] + bv[4 * g], a[4 * g + 1] + bv[4 * g + 1], a[4 * g + 2] + bv[4 * g + 2],
-                                           a[4 * g + 3] + bv[4 * g + 3]);
-                    if (ok) {
+                for (int g = 0; g < 4; ++g)
+                    *reinterpret_cast<float4*>(es + wr_row + (((2 * g + h) ^ wr_sw) << 4)) =
+                        make_float4(a[4 * g], a[4 * g + 1], a[4 * g + 2], a[4 * g + 3]);
+                wave_lds_sync();
+                const int mb = m0 + wm * 128 + ms * 32;
+#pragma unroll 2
+                for (int i = 0; i < 4; ++i) {
+                    const int r = rd_row + 8 * i;
+                    float4 v = *reinterpret_cast<const float4*>(es + r * 128 + ((rd_c ^ (r & 7)) << 4));
+                    const int m = mb + r;
+                    if (m < p.M && live) {
+                        const int n = nb + rd_c * 4;
                         if (p.add16) {
                             const uint2 t2 = *reinterpret_cast<const uint2*>(p.add16 + static_cast<int64_t>(m) * p.ld16 + n);
                             float e0, e1, e2, e3;
@@ -86,29 +113,48 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, const f32x16 
                             const float4 t4 = *reinterpret_cast<const float4*>(p.add32 + static_cast<int64_t>(m) * p.ld32 + n);
                             v.x += t4.x; v.y += t4.y; v.z += t4.z; v.w += t4.w;
                         }
-                        *reinterpret_cast<float4*>(orow + n) = v;
+                        store16(reinterpret_cast<float*>(p.out) + static_cast<int64_t>(m) * p.ldo + n,
+                                make_uint4(__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)), policy);
                     }
                 }
-            } else {
-                uint16_t* orow = reinterpret_cast<uint16_t*>(p.out) + static_cast<int64_t>(m) * p.ldo;
+                wave_lds_sync();
+            }
+        }
+    } else {
+#pragma unroll
+        for (int ms = 0; ms < 4; ++ms) {
+#pragma unroll
+            for (int ns = 0; ns < 2; ++ns) {
+                const f32x16 a = acc[ns][ms];
 #pragma unroll
                 for (int gp = 0; gp < 2; ++gp) {
                     float v[8];
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) v[e] = a[8 * gp + e] + bv[8 * gp + e];
+                    for (int e = 0; e < 8; ++e) v[e] = a[8 * gp + e];
                     if constexpr (EPI == EPI_BF16_RELU) {
 #pragma unroll
                         for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.0f);
                     }
                     uint32_t lo0 = pack_elem2<F16>(v[0], v[1]), lo1 = pack_elem2<F16>(v[2], v[3]);
                     uint32_t hi0 = pack_elem2<F16>(v[4], v[5]), hi1 = pack_elem2<F16>(v[6], v[7]);
-                    // lanes 32..63 of lo swap with lanes 0..31 of hi: h = 0 ends with n 0..7, h = 1 with n 8..15
+                    // lanes 32..63 of lo swap with lanes 0..31 of hi: h = 0 ends with columns 0..7, h = 1 with 8..15
                     auto s0 = __builtin_amdgcn_permlane32_swap(lo0, hi0, false, false);
                     auto s1 = __builtin_amdgcn_permlane32_swap(lo1, hi1, false, false);
-                    if (ok)
-                        *reinterpret_cast<uint4*>(orow + nb + 16 * gp + 8 * h) = make_uint4(s0[0], s1[0], s0[1], s1[1]);
+                    const int chunk = ns * 4 + 2 * gp + h;  // 16-byte chunk of the 128-byte (64-column) row
+                    *reinterpret_cast<uint4*>(es + wr_row + ((chunk ^ wr_sw) << 4)) = make_uint4(s0[0], s1[0], s0[1], s1[1]);
                 }
             }
+            wave_lds_sync();
+            const int mb = m0 + wm * 128 + ms * 32;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int r = rd_row + 8 * i;
+                const uint4 v = *reinterpret_cast<const uint4*>(es + r * 128 + ((rd_c ^ (r & 7)) << 4));
+                const int m = mb + r;
+                if (m < p.M && live)
+                    store16(reinterpret_cast<uint16_t*>(p.out) + static_cast<int64_t>(m) * p.ldo + n0 + wn * 64 + rd_c * 8, v, policy);
+            }
+            wave_lds_sync();
         }
     }
 }
@@ -198,15 +244,26 @@ __global__ __launch_bounds__(kGemmThreads) void gemm_bf16_kernel(const GemmParam
     const int a_row_off = (wm * 64 + l31) * 128;                   // + a * kHalfBytes + ms * 4096
     const int b_row_off = 2 * kHalfBytes + (wn * 32 + l31) * 128;  // + b * kHalfBytes
 
+    // accumulators start from the bias: register e of acc[b][*] is column n0 + wn * 64 + b * 32 + 8 (e >> 2) + 4 h + (e & 3)
+    auto init_acc = [&](f32x16 (&acc_)[2][4], int tile) {
+        const int tn_ = tile % p.n_tiles_n;
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            f32x16 bvec;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const float4 t4 = *reinterpret_cast<const float4*>(p.bias + tn_ * BN + wn * 64 + b * 32 + 8 * g + 4 * (lane >> 5));
+                bvec[4 * g] = t4.x; bvec[4 * g + 1] = t4.y; bvec[4 * g + 2] = t4.z; bvec[4 * g + 3] = t4.w;
+            }
+#pragma unroll
+            for (int ms = 0; ms < 4; ++ms) acc_[b][ms] = bvec;
+        }
+    };
+
     u16x8 ra[2][4];    // activation fragments [ms][s] of the current A half
     u16x8 rb[2][4];    // weight fragments [b][s]: rb[0] always holds B0, rb[1] always holds B1
     f32x16 acc[2][4];  // [b][a * 2 + ms]
-#pragma unroll
-    for (int b = 0; b < 2; ++b)
-#pragma unroll
-        for (int ms = 0; ms < 4; ++ms)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[b][ms][e] = 0.0f;
+    init_acc(acc, first_tile);
 
     auto read_a = [&](int a, int slot, int ms, int s) {
         ra[ms][s] = *reinterpret_cast<const u16x8*>(smem + slot * kSlotBytes + a * kHalfBytes + a_row_off + ms * 4096 + coff[s]);
@@ -268,15 +325,10 @@ __global__ __launch_bounds__(kGemmThreads) void gemm_bf16_kernel(const GemmParam
         kt_in_tile += 2;
         if (kt_in_tile == nk) {  // this output tile is complete: store it while the next tile's loads fly
             const int tm = cur_tile / p.n_tiles_n, tn = cur_tile - tm * p.n_tiles_n;
-            gemm_epilogue<EPI, F16>(p, acc, tm * BM, tn * BN, wm, wn, l31, h);
-#pragma unroll
-            for (int b = 0; b < 2; ++b)
-#pragma unroll
-                for (int ms = 0; ms < 4; ++ms)
-#pragma unroll
-                    for (int e = 0; e < 16; ++e) acc[b][ms][e] = 0.0f;
+            gemm_epilogue<EPI, F16>(p, acc, tm * BM, tn * BN, wm, wn, lane, smem + kRingBytes + wave * 4096);
             kt_in_tile = 0;
             cur_tile += wgs_of_xcd;
+            if (g + 2 < n_kt) init_acc(acc, cur_tile);
         }
     }
 #undef PHASE
@@ -299,7 +351,7 @@ int32_t launch_gemm(asrfe_ctx* ctx, const GemmParams& pin, int epi, hipStream_t 
                               reinterpret_cast<const void*>(gemm_bf16_kernel<EPI_F32_ADD, true>)};
         for (const void* f : fns)
             if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, kGemmLds) != hipSuccess)
-                return set_err(ctx, ASRFE_ERR_HIP, "gemm: cannot raise the dynamic LDS limit to 128 KiB");
+                return set_err(ctx, ASRFE_ERR_HIP, "gemm: cannot raise the dynamic LDS limit to 160 KiB");
         attr_done = true;
     }
     const int n_tiles = p.n_tiles_m * p.n_tiles_n;
