@@ -27,7 +27,7 @@ constexpr int kVTileBytes = 128 * kVRow;
                                      (__attribute__((address_space(3))) void*)(lptr), 16, 0, 0)
 
 template <bool F16>
-__global__ __launch_bounds__(kAttnThreads) void attn_kernel(const AttnParams p) {
+__global__ __launch_bounds__(kAttnThreads, 2) void attn_kernel(const AttnParams p) {
     // two K/V buffers: tile kt + 1 is fetched while tile kt is multiplied
     __shared__ __attribute__((aligned(16))) char smem[2 * (kKTileBytes + kVTileBytes)];
     const int tid = threadIdx.x;
