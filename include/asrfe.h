@@ -155,7 +155,7 @@ typedef struct asrfe_profile {
     float total_ms[ASRFE_PROF_KINDS];
 } asrfe_profile;
 /* kinds: 0 fbank, 1 frontend(fused), 2 lfr_cmvn, 3 pe_table, 4 layernorm, 5 gemm_qkv, 6 fsmn,
- *        7 attention, 8 gemm_out, 9 gemm_ffn1, 10 gemm_ffn2, 11 reserved */
+ *        7 attention, 8 gemm_out, 9 gemm_ffn1, 10 gemm_ffn2, 11 ffn_fused (norm2 + both linears + next norm1) */
 int32_t asrfe_profile_begin(asrfe_ctx* ctx, int32_t max_launches);
 int32_t asrfe_profile_end(asrfe_ctx* ctx, asrfe_profile* out);
 

@@ -58,7 +58,7 @@ class Config(C.Structure):
 
 
 PROF_KINDS = ["fbank", "frontend", "lfr_cmvn", "pe_table", "layernorm", "gemm_qkv", "fsmn", "attention", "gemm_out",
-              "gemm_ffn1", "gemm_ffn2", "reserved"]
+              "gemm_ffn1", "gemm_ffn2", "ffn_fused"]
 
 
 class Profile(C.Structure):

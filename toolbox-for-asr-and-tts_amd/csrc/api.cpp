@@ -2,6 +2,7 @@
 // The compute calls only validate, fill a parameter block and launch; they never allocate.
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 
@@ -166,6 +167,10 @@ extern "C" int32_t asrfe_create(const asrfe_config* cfg, asrfe_ctx** out) {
     ctx->cmvn_loaded = false;
     ctx->enc_loaded = false;
     ctx->kin_pad = (cfg->enc_input_size + 127) / 128 * 128;
+    {
+        const char* e = std::getenv("ASRFE_UNFUSED_FFN");
+        ctx->unfused_ffn = e && e[0] == '1';
+    }
     ctx->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     ctx->after_g = ctx->after_b = ctx->pe_inv = nullptr;
     std::memset(&ctx->tab, 0, sizeof(ctx->tab));
@@ -354,6 +359,20 @@ static int32_t up_bf16(asrfe_ctx* ctx, const HostTensor* t, int k_pad, uint16_t*
     return upload(ctx, v, dev);
 }
 
+// same as up_bf16 for k_pad == k, with column p of the result taken from column swap23(p) of the source
+static int32_t up_bf16_perm(asrfe_ctx* ctx, const HostTensor* t, uint16_t** dev) {
+    const int64_t n = t->shape[0], k = t->shape[1];
+    const bool f16 = ctx->cfg.enc_compute_dtype == ASRFE_DT_F16;
+    std::vector<uint16_t> v(static_cast<size_t>(n) * k, 0);
+    for (int64_t r = 0; r < n; ++r)
+        for (int64_t c = 0; c < k; ++c) {
+            const int64_t src = (c & ~int64_t{12}) | ((c & 4) << 1) | ((c & 8) >> 1);
+            const float w = t->data[r * k + src];
+            v[r * k + c] = f16 ? f16_rne(w) : bf16_rne(w);
+        }
+    return upload(ctx, v, dev);
+}
+
 extern "C" int32_t asrfe_load_encoder_weights(asrfe_ctx* ctx, const asrfe_tensor_desc* descs, int32_t n) {
     if (!ctx || !descs || n <= 0) return set_err(ctx, ASRFE_ERR_BAD_ARG, "asrfe_load_encoder_weights: null argument");
     if (ctx->enc_loaded) return set_err(ctx, ASRFE_ERR_BAD_ARG, "asrfe_load_encoder_weights: weights already loaded");
@@ -393,9 +412,9 @@ extern "C" int32_t asrfe_load_encoder_weights(asrfe_ctx* ctx, const asrfe_tensor
         if ((rc = need(ctx, m, p + ".self_attn.linear_out.bias", {d}, &t)) || (rc = up_f32(ctx, t, &L.b_out))) return rc;
         if ((rc = need(ctx, m, p + ".norm2.weight", {d}, &t)) || (rc = up_f32(ctx, t, &L.ln2_g))) return rc;
         if ((rc = need(ctx, m, p + ".norm2.bias", {d}, &t)) || (rc = up_f32(ctx, t, &L.ln2_b))) return rc;
-        if ((rc = need(ctx, m, p + ".feed_forward.w_1.weight", {ff, d}, &t)) || (rc = up_bf16(ctx, t, static_cast<int>(d), &L.w_ffn1))) return rc;
+        if ((rc = need(ctx, m, p + ".feed_forward.w_1.weight", {ff, d}, &t)) || (rc = up_bf16(ctx, t, static_cast<int>(d), &L.w_ffn1)) || (rc = up_bf16_perm(ctx, t, &L.w_ffn1p))) return rc;
         if ((rc = need(ctx, m, p + ".feed_forward.w_1.bias", {ff}, &t)) || (rc = up_f32(ctx, t, &L.b_ffn1))) return rc;
-        if ((rc = need(ctx, m, p + ".feed_forward.w_2.weight", {d, ff}, &t)) || (rc = up_bf16(ctx, t, static_cast<int>(ff), &L.w_ffn2))) return rc;
+        if ((rc = need(ctx, m, p + ".feed_forward.w_2.weight", {d, ff}, &t)) || (rc = up_bf16(ctx, t, static_cast<int>(ff), &L.w_ffn2)) || (rc = up_bf16_perm(ctx, t, &L.w_ffn2p))) return rc;
         if ((rc = need(ctx, m, p + ".feed_forward.w_2.bias", {d}, &t)) || (rc = up_f32(ctx, t, &L.b_ffn2))) return rc;
     }
     const HostTensor* t;

@@ -61,6 +61,10 @@ struct LayerWeights {
     float* ln2_g; float* ln2_b;        // [512]
     uint16_t* w_ffn1; float* b_ffn1;   // bf16 [2048][512]
     uint16_t* w_ffn2; float* b_ffn2;   // bf16 [512][2048]
+    // the same two matrices with the columns inside every group of 16 stored in the order the fused
+    // feed-forward kernel visits k (bits 2 and 3 of the column index swapped)
+    uint16_t* w_ffn1p;
+    uint16_t* w_ffn2p;
 };
 
 }  // namespace asrfe
@@ -73,6 +77,7 @@ struct asrfe_ctx {
     bool enc_loaded;
     int kin_pad;  // layer-0 K padded to a multiple of 128
     int num_cus;  // compute units of the device (persistent kernels launch one workgroup per CU)
+    bool unfused_ffn;  // ASRFE_UNFUSED_FFN=1 in the environment: LayerNorm + two GEMM launches instead of the fused kernel
     std::vector<asrfe::LayerWeights> layers;
     float* after_g;
     float* after_b;
@@ -88,7 +93,7 @@ struct asrfe_ctx {
 
 namespace asrfe {
 enum ProfKind { PK_FBANK = 0, PK_FRONTEND, PK_LFR_CMVN, PK_PE, PK_LN, PK_GEMM_QKV, PK_FSMN, PK_ATTN, PK_GEMM_OUT,
-                PK_GEMM_FFN1, PK_GEMM_FFN2, PK_RESERVED };
+                PK_GEMM_FFN1, PK_GEMM_FFN2, PK_FFN_FUSED };
 // Brackets one launch with events when profiling is on; a no-op otherwise.
 struct ProfScope {
     asrfe_ctx* ctx;

@@ -82,14 +82,15 @@ int32_t encoder_forward(asrfe_ctx* ctx, const float* feats, const int32_t* lens,
     for (int li = 0; li < c.enc_num_blocks; ++li) {
         const LayerWeights& L = ctx->layers[li];
         const int kin = li == 0 ? ctx->kin_pad : 512;
-        {
-        ProfScope ps(ctx, PK_LN, s);
+        // norm1: layer 0 normalises the scaled, position-coded input; later layers get h from the previous
+        // layer's fused feed-forward kernel
         if (li == 0) {
+            ProfScope ps(ctx, PK_LN, s);
             rc = launch_ln_input(ctx, feats, bf.pe, std::sqrt(static_cast<float>(c.enc_output_size)), L.ln1_g, L.ln1_b,
                                  c.enc_ln_eps, M, Tp, c.enc_input_size, bf.h, kin, s);
-        } else {
+        } else if (ctx->unfused_ffn) {
+            ProfScope ps(ctx, PK_LN, s);
             rc = launch_ln512(ctx, bf.x, L.ln1_g, L.ln1_b, c.enc_ln_eps, M, bf.h, s);
-        }
         }
         if (rc) return rc;
 
@@ -116,6 +117,21 @@ int32_t encoder_forward(asrfe_ctx* ctx, const float* feats, const int32_t* lens,
         g.add32 = li == 0 ? nullptr : bf.x; g.ld32 = 512;
         { ProfScope ps(ctx, PK_GEMM_OUT, s); rc = launch_gemm(ctx, g, EPI_F32_ADD, s); }
         if (rc) return rc;
+
+        if (!ctx->unfused_ffn) {
+            // x = x + FFN(norm2(x)) and h = norm1 of the next layer, one kernel
+            const bool has_next = li + 1 < c.enc_num_blocks;
+            FfnParams f{};
+            f.x = bf.x; f.x_out = bf.x; f.ln_g = L.ln2_g; f.ln_b = L.ln2_b;
+            f.w1 = L.w_ffn1p; f.b1 = L.b_ffn1; f.w2 = L.w_ffn2p; f.b2 = L.b_ffn2;
+            f.y = has_next ? bf.h : nullptr; f.ldy = 512;
+            f.y_g = has_next ? ctx->layers[li + 1].ln1_g : nullptr;
+            f.y_b = has_next ? ctx->layers[li + 1].ln1_b : nullptr;
+            f.eps = c.enc_ln_eps; f.M = M; f.ff = ff;
+            { ProfScope ps(ctx, PK_FFN_FUSED, s); rc = launch_ffn(ctx, f, s); }
+            if (rc) return rc;
+            continue;
+        }
 
         { ProfScope ps(ctx, PK_LN, s); rc = launch_ln512(ctx, bf.x, L.ln2_g, L.ln2_b, c.enc_ln_eps, M, bf.h, s); }
         if (rc) return rc;

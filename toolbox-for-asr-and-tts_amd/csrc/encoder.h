@@ -33,6 +33,26 @@ int32_t launch_ln512(asrfe_ctx* ctx, const float* x, const float* g, const float
 int32_t launch_ln_final(asrfe_ctx* ctx, const float* x, const float* g, const float* bta, float eps, int B, int Tp,
                         const int32_t* lens, void* out, int out_dtype, hipStream_t s);
 
+// Fused feed-forward block: x_out = x + W2 relu(W1 LN(x) + b1) + b2, and optionally y = LN'(x_out) as 16-bit.
+// w1 / w2 are the column-permuted copies (LayerWeights::w_ffn1p / w_ffn2p).  x_out may alias x.
+struct FfnParams {
+    const float* x;        // [M][512]
+    float* x_out;          // [M][512]
+    const float* ln_g;     // LayerNorm in front of the block (norm2)
+    const float* ln_b;
+    const uint16_t* w1;    // [ff][512], columns permuted
+    const float* b1;       // [ff]
+    const uint16_t* w2;    // [512][ff], columns permuted
+    const float* b2;       // [512]
+    void* y;               // optional 16-bit [M][ldy] in the compute dtype
+    int ldy;
+    const float* y_g;      // LayerNorm applied to x_out for y (the next layer's norm1)
+    const float* y_b;
+    float eps;
+    int M, ff;
+};
+int32_t launch_ffn(asrfe_ctx* ctx, const FfnParams& p, hipStream_t s);
+
 // FSMN memory block on V (columns 1024..1535 of qkv) and the transposed V copy for attention
 int32_t launch_fsmn(asrfe_ctx* ctx, const uint16_t* qkv, int ld_qkv, const float* w /*[11][512]*/, const int32_t* lens,
                     int B, int Tp, int Tk, uint16_t* fsmn /*[B*Tp][512]*/, uint16_t* vt /*[B][512][Tk]*/, hipStream_t s);
