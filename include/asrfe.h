@@ -168,6 +168,13 @@ int32_t asrfe_debug_gemm(asrfe_ctx* ctx, const void* a, int32_t lda, const void*
                          int32_t m, int32_t n, int32_t k, void* out, int32_t ldo, const void* add16,
                          const float* add32, int32_t epi, int32_t flags, void* stream);
 
+/* Kernel-level test hook (no counterpart in the reference): one launch of the fused feed-forward kernel of
+ * encoder layer `layer` on x [m][512] float32:  x_out = x + W2 relu(W1 norm2(x) + b1) + b2 (x_out may alias x) and,
+ * when y is not NULL, y [m][512] = LayerNorm(x_out) in the 16-bit compute dtype with the next layer's norm1
+ * parameters (after_norm's for the last layer).  flags != 0 are timing experiments that produce wrong results. */
+int32_t asrfe_debug_ffn(asrfe_ctx* ctx, int32_t layer, const float* x, float* x_out, void* y, int32_t m,
+                        int32_t flags, void* stream);
+
 /* Text of the last error on this context (or of the last failed asrfe_create when ctx is NULL). */
 const char* asrfe_last_error(const asrfe_ctx* ctx);
 const char* asrfe_version(void);

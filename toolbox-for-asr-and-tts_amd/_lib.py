@@ -99,6 +99,8 @@ SIGNATURES = {
     "asrfe_debug_gemm": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32,
                                      C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32,
                                      C.c_int32, C.c_void_p]),
+    "asrfe_debug_ffn": (C.c_int32, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32,
+                                    C.c_void_p]),
     "asrfe_last_error": (C.c_char_p, [C.c_void_p]),
     "asrfe_version": (C.c_char_p, []),
 }

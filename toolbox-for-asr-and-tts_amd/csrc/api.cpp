@@ -7,6 +7,7 @@
 #include <map>
 
 #include "common.h"
+#include "encoder.h"
 #include "gemm.h"
 
 using namespace asrfe;
@@ -359,17 +360,56 @@ static int32_t up_bf16(asrfe_ctx* ctx, const HostTensor* t, int k_pad, uint16_t*
     return upload(ctx, v, dev);
 }
 
-// same as up_bf16 for k_pad == k, with column p of the result taken from column swap23(p) of the source
-static int32_t up_bf16_perm(asrfe_ctx* ctx, const HostTensor* t, uint16_t** dev) {
-    const int64_t n = t->shape[0], k = t->shape[1];
-    const bool f16 = ctx->cfg.enc_compute_dtype == ASRFE_DT_F16;
-    std::vector<uint16_t> v(static_cast<size_t>(n) * k, 0);
-    for (int64_t r = 0; r < n; ++r)
-        for (int64_t c = 0; c < k; ++c) {
-            const int64_t src = (c & ~int64_t{12}) | ((c & 4) << 1) | ((c & 8) >> 1);
-            const float w = t->data[r * k + src];
-            v[r * k + c] = f16 ? f16_rne(w) : bf16_rne(w);
+// A LayerNorm's scale and shift in front of a linear layer are folded into it:
+//     W (g * n + b) + c  =  (W diag(g)) n + (W b + c),        n = the normalised row,
+// so the LayerNorm kernels (and the fused feed-forward kernel) emit n without touching g and b.
+static void fold_layernorm(const HostTensor* w, const HostTensor* c, const HostTensor* g, const HostTensor* b,
+                           std::vector<float>& wf, std::vector<float>& cf) {
+    const int64_t n = w->shape[0], k = w->shape[1];
+    wf.resize(static_cast<size_t>(n * k));
+    cf.resize(static_cast<size_t>(n));
+    for (int64_t r = 0; r < n; ++r) {
+        double acc = c->data[r];
+        for (int64_t i = 0; i < k; ++i) {
+            wf[r * k + i] = w->data[r * k + i] * g->data[i];
+            acc += static_cast<double>(w->data[r * k + i]) * b->data[i];
         }
+        cf[r] = static_cast<float>(acc);
+    }
+}
+
+// W1 [ff][512] and W2 [512][ff] as the piece stream of the fused feed-forward kernel: for every chunk j of 64
+// hidden units, four images of W1[64 j .. +64][128 ks .. +128] (64 rows of 256 bytes, 16-byte slot cs of row r
+// holding source chunk cs ^ (r & 15)) followed by four images of W2[128 nq .. +128][64 j .. +64] (128 rows of
+// 128 bytes, slot cs of row r holding source chunk cs ^ ((r >> 1) & 7)).  Inside every group of 16 columns the
+// k order is p -> swap of bits 2 and 3 of p, the order in which accumulator registers feed the next MFMA.
+static int32_t up_ffn_stream(asrfe_ctx* ctx, const HostTensor* w1, const HostTensor* w2, uint16_t** dev) {
+    const int64_t ff = w1->shape[0], d = w1->shape[1];
+    const bool f16 = ctx->cfg.enc_compute_dtype == ASRFE_DT_F16;
+    auto cvt = [&](float w) { return f16 ? f16_rne(w) : bf16_rne(w); };
+    auto swap23 = [](int64_t c) { return (c & ~int64_t{12}) | ((c & 4) << 1) | ((c & 8) >> 1); };
+    std::vector<uint16_t> v(static_cast<size_t>(2 * ff * d), 0);
+    const int64_t nch = ff / 64;
+    for (int64_t j = 0; j < nch; ++j) {
+        for (int64_t ks = 0; ks < 4; ++ks) {
+            uint16_t* img = v.data() + (8 * j + ks) * 8192;
+            for (int64_t r = 0; r < 64; ++r)
+                for (int64_t cs = 0; cs < 16; ++cs)
+                    for (int64_t e = 0; e < 8; ++e) {
+                        const int64_t kp = 128 * ks + 8 * (cs ^ (r & 15)) + e;
+                        img[(r * 16 + cs) * 8 + e] = cvt(w1->data[(64 * j + r) * d + swap23(kp)]);
+                    }
+        }
+        for (int64_t nq = 0; nq < 4; ++nq) {
+            uint16_t* img = v.data() + (8 * j + 4 + nq) * 8192;
+            for (int64_t r = 0; r < 128; ++r)
+                for (int64_t cs = 0; cs < 8; ++cs)
+                    for (int64_t e = 0; e < 8; ++e) {
+                        const int64_t cp = 64 * j + 8 * (cs ^ ((r >> 1) & 7)) + e;
+                        img[(r * 8 + cs) * 8 + e] = cvt(w2->data[(128 * nq + r) * ff + swap23(cp)]);
+                    }
+        }
+    }
     return upload(ctx, v, dev);
 }
 
@@ -397,10 +437,17 @@ extern "C" int32_t asrfe_load_encoder_weights(asrfe_ctx* ctx, const asrfe_tensor
         const int kpad = li == 0 ? ctx->kin_pad : static_cast<int>(d);
         LayerWeights& L = ctx->layers[li];
         const HostTensor* t;
-        if ((rc = need(ctx, m, p + ".norm1.weight", {din}, &t)) || (rc = up_f32(ctx, t, &L.ln1_g))) return rc;
-        if ((rc = need(ctx, m, p + ".norm1.bias", {din}, &t)) || (rc = up_f32(ctx, t, &L.ln1_b))) return rc;
-        if ((rc = need(ctx, m, p + ".self_attn.linear_q_k_v.weight", {3 * d, din}, &t)) || (rc = up_bf16(ctx, t, kpad, &L.w_qkv))) return rc;
-        if ((rc = need(ctx, m, p + ".self_attn.linear_q_k_v.bias", {3 * d}, &t)) || (rc = up_f32(ctx, t, &L.b_qkv))) return rc;
+        const HostTensor *tg, *tb, *tw, *tc;
+        std::vector<float> wfold, cfold;
+        if ((rc = need(ctx, m, p + ".norm1.weight", {din}, &tg)) || (rc = need(ctx, m, p + ".norm1.bias", {din}, &tb)) ||
+            (rc = need(ctx, m, p + ".self_attn.linear_q_k_v.weight", {3 * d, din}, &tw)) ||
+            (rc = need(ctx, m, p + ".self_attn.linear_q_k_v.bias", {3 * d}, &tc)))
+            return rc;
+        fold_layernorm(tw, tc, tg, tb, wfold, cfold);
+        {
+            const HostTensor view{wfold.data(), tw->shape};
+            if ((rc = up_bf16(ctx, &view, kpad, &L.w_qkv)) || (rc = upload(ctx, cfold, &L.b_qkv))) return rc;
+        }
         if ((rc = need(ctx, m, p + ".self_attn.fsmn_block.weight", {d, 1, ks}, &t))) return rc;
         {
             std::vector<float> w(static_cast<size_t>(ks) * d);
@@ -410,11 +457,16 @@ extern "C" int32_t asrfe_load_encoder_weights(asrfe_ctx* ctx, const asrfe_tensor
         }
         if ((rc = need(ctx, m, p + ".self_attn.linear_out.weight", {d, d}, &t)) || (rc = up_bf16(ctx, t, static_cast<int>(d), &L.w_out))) return rc;
         if ((rc = need(ctx, m, p + ".self_attn.linear_out.bias", {d}, &t)) || (rc = up_f32(ctx, t, &L.b_out))) return rc;
-        if ((rc = need(ctx, m, p + ".norm2.weight", {d}, &t)) || (rc = up_f32(ctx, t, &L.ln2_g))) return rc;
-        if ((rc = need(ctx, m, p + ".norm2.bias", {d}, &t)) || (rc = up_f32(ctx, t, &L.ln2_b))) return rc;
-        if ((rc = need(ctx, m, p + ".feed_forward.w_1.weight", {ff, d}, &t)) || (rc = up_bf16(ctx, t, static_cast<int>(d), &L.w_ffn1)) || (rc = up_bf16_perm(ctx, t, &L.w_ffn1p))) return rc;
-        if ((rc = need(ctx, m, p + ".feed_forward.w_1.bias", {ff}, &t)) || (rc = up_f32(ctx, t, &L.b_ffn1))) return rc;
-        if ((rc = need(ctx, m, p + ".feed_forward.w_2.weight", {d, ff}, &t)) || (rc = up_bf16(ctx, t, static_cast<int>(ff), &L.w_ffn2)) || (rc = up_bf16_perm(ctx, t, &L.w_ffn2p))) return rc;
+        if ((rc = need(ctx, m, p + ".norm2.weight", {d}, &tg)) || (rc = need(ctx, m, p + ".norm2.bias", {d}, &tb)) ||
+            (rc = need(ctx, m, p + ".feed_forward.w_1.weight", {ff, d}, &tw)) ||
+            (rc = need(ctx, m, p + ".feed_forward.w_1.bias", {ff}, &tc)))
+            return rc;
+        fold_layernorm(tw, tc, tg, tb, wfold, cfold);
+        const HostTensor w1view{wfold.data(), tw->shape};
+        if ((rc = up_bf16(ctx, &w1view, static_cast<int>(d), &L.w_ffn1)) || (rc = upload(ctx, cfold, &L.b_ffn1))) return rc;
+        if ((rc = need(ctx, m, p + ".feed_forward.w_2.weight", {d, ff}, &t)) || (rc = up_bf16(ctx, t, static_cast<int>(ff), &L.w_ffn2))) return rc;
+        if (d != 512 || ff % 64 != 0) return set_err(ctx, ASRFE_ERR_SHAPE, "asrfe_load_encoder_weights: the fused feed-forward kernel needs d = 512 and linear_units % 64 == 0");
+        if ((rc = up_ffn_stream(ctx, &w1view, t, &L.w_ffn_stream))) return rc;
         if ((rc = need(ctx, m, p + ".feed_forward.w_2.bias", {d}, &t)) || (rc = up_f32(ctx, t, &L.b_ffn2))) return rc;
     }
     const HostTensor* t;
@@ -514,6 +566,20 @@ extern "C" int32_t asrfe_debug_gemm(asrfe_ctx* ctx, const void* a, int32_t lda, 
     g.add32 = add32; g.ld32 = ldo;
     g.flags = flags;
     return launch_gemm(ctx, g, epi, static_cast<hipStream_t>(stream));
+}
+
+extern "C" int32_t asrfe_debug_ffn(asrfe_ctx* ctx, int32_t layer, const float* x, float* x_out, void* y, int32_t m,
+                                   int32_t flags, void* stream) {
+    if (!ctx || !x || !x_out) return set_err(ctx, ASRFE_ERR_BAD_ARG, "asrfe_debug_ffn: null argument");
+    if (!ctx->enc_loaded) return set_err(ctx, ASRFE_ERR_NOT_LOADED, "asrfe_debug_ffn: encoder weights not loaded");
+    if (layer < 0 || layer >= ctx->cfg.enc_num_blocks) return set_err(ctx, ASRFE_ERR_BAD_ARG, "asrfe_debug_ffn: no such layer");
+    const LayerWeights& L = ctx->layers[layer];
+    FfnParams f{};
+    f.x = x; f.x_out = x_out;
+    f.wstream = L.w_ffn_stream; f.b1 = L.b_ffn1; f.b2 = L.b_ffn2;
+    f.y = y; f.ldy = 512;
+    f.eps = ctx->cfg.enc_ln_eps; f.M = m; f.ff = ctx->cfg.enc_linear_units; f.flags = flags;
+    return launch_ffn(ctx, f, static_cast<hipStream_t>(stream));
 }
 
 // ---- encoder entry points ----------------------------------------------------------------------

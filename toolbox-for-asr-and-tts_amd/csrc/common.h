@@ -54,17 +54,16 @@ struct FbankParams {
 // ---- encoder ----------------------------------------------------------------------------------
 struct LayerWeights {
     // device pointers (library-owned)
-    float* ln1_g; float* ln1_b;        // [din]
-    uint16_t* w_qkv; float* b_qkv;     // bf16 [1536][kin_pad], f32 [1536]
+    // norm1 and norm2 have no parameters of their own here: their scale and shift are folded into the linear
+    // layer behind them (w_qkv / b_qkv and w_ffn1 / b_ffn1) when the weights are loaded
+    uint16_t* w_qkv; float* b_qkv;     // 16-bit [1536][kin_pad], f32 [1536]
     float* w_fsmn;                     // f32 [11][512]  (tap-major)
     uint16_t* w_out; float* b_out;     // bf16 [512][512]
-    float* ln2_g; float* ln2_b;        // [512]
     uint16_t* w_ffn1; float* b_ffn1;   // bf16 [2048][512]
     uint16_t* w_ffn2; float* b_ffn2;   // bf16 [512][2048]
-    // the same two matrices with the columns inside every group of 16 stored in the order the fused
-    // feed-forward kernel visits k (bits 2 and 3 of the column index swapped)
-    uint16_t* w_ffn1p;
-    uint16_t* w_ffn2p;
+    // both matrices again as the stream of 16 KiB LDS images the fused feed-forward kernel consumes, in the
+    // order it consumes them (layout: ffn.hip)
+    uint16_t* w_ffn_stream;
 };
 
 }  // namespace asrfe

@@ -86,11 +86,11 @@ int32_t encoder_forward(asrfe_ctx* ctx, const float* feats, const int32_t* lens,
         // layer's fused feed-forward kernel
         if (li == 0) {
             ProfScope ps(ctx, PK_LN, s);
-            rc = launch_ln_input(ctx, feats, bf.pe, std::sqrt(static_cast<float>(c.enc_output_size)), L.ln1_g, L.ln1_b,
+            rc = launch_ln_input(ctx, feats, bf.pe, std::sqrt(static_cast<float>(c.enc_output_size)), nullptr, nullptr,
                                  c.enc_ln_eps, M, Tp, c.enc_input_size, bf.h, kin, s);
         } else if (ctx->unfused_ffn) {
             ProfScope ps(ctx, PK_LN, s);
-            rc = launch_ln512(ctx, bf.x, L.ln1_g, L.ln1_b, c.enc_ln_eps, M, bf.h, s);
+            rc = launch_ln512(ctx, bf.x, nullptr, nullptr, c.enc_ln_eps, M, bf.h, s);
         }
         if (rc) return rc;
 
@@ -119,21 +119,19 @@ int32_t encoder_forward(asrfe_ctx* ctx, const float* feats, const int32_t* lens,
         if (rc) return rc;
 
         if (!ctx->unfused_ffn) {
-            // x = x + FFN(norm2(x)) and h = norm1 of the next layer, one kernel
+            // x = x + FFN(norm2(x)) and h = the next layer's normalised input, one kernel
             const bool has_next = li + 1 < c.enc_num_blocks;
             FfnParams f{};
-            f.x = bf.x; f.x_out = bf.x; f.ln_g = L.ln2_g; f.ln_b = L.ln2_b;
-            f.w1 = L.w_ffn1p; f.b1 = L.b_ffn1; f.w2 = L.w_ffn2p; f.b2 = L.b_ffn2;
+            f.x = bf.x; f.x_out = bf.x;
+            f.wstream = L.w_ffn_stream; f.b1 = L.b_ffn1; f.b2 = L.b_ffn2;
             f.y = has_next ? bf.h : nullptr; f.ldy = 512;
-            f.y_g = has_next ? ctx->layers[li + 1].ln1_g : nullptr;
-            f.y_b = has_next ? ctx->layers[li + 1].ln1_b : nullptr;
             f.eps = c.enc_ln_eps; f.M = M; f.ff = ff;
             { ProfScope ps(ctx, PK_FFN_FUSED, s); rc = launch_ffn(ctx, f, s); }
             if (rc) return rc;
             continue;
         }
 
-        { ProfScope ps(ctx, PK_LN, s); rc = launch_ln512(ctx, bf.x, L.ln2_g, L.ln2_b, c.enc_ln_eps, M, bf.h, s); }
+        { ProfScope ps(ctx, PK_LN, s); rc = launch_ln512(ctx, bf.x, nullptr, nullptr, c.enc_ln_eps, M, bf.h, s); }
         if (rc) return rc;
 
         g = GemmParams{};

@@ -21,7 +21,8 @@ int32_t launch_attention(asrfe_ctx* ctx, const AttnParams& p, hipStream_t s);
 // pe[t][i] = sin((t+1) inv[i]) for i < D/2, cos((t+1) inv[i - D/2]) otherwise
 int32_t launch_pe_table(asrfe_ctx* ctx, const float* inv, int Tp, int D, float* pe, hipStream_t s);
 
-// h = LayerNorm(feats * xscale + pe[t]) over D columns -> bf16 [M][ldh], columns D..ldh-1 zero
+// h = LayerNorm(feats * xscale + pe[t]) over D columns -> 16-bit [M][ldh], columns D..ldh-1 zero; g / bta may be
+// null (scale 1, shift 0)
 int32_t launch_ln_input(asrfe_ctx* ctx, const float* feats, const float* pe, float xscale, const float* g,
                         const float* bta, float eps, int M, int Tp, int D, uint16_t* hout, int ldh, hipStream_t s);
 
@@ -33,23 +34,21 @@ int32_t launch_ln512(asrfe_ctx* ctx, const float* x, const float* g, const float
 int32_t launch_ln_final(asrfe_ctx* ctx, const float* x, const float* g, const float* bta, float eps, int B, int Tp,
                         const int32_t* lens, void* out, int out_dtype, hipStream_t s);
 
-// Fused feed-forward block: x_out = x + W2 relu(W1 LN(x) + b1) + b2, and optionally y = LN'(x_out) as 16-bit.
-// w1 / w2 are the column-permuted copies (LayerWeights::w_ffn1p / w_ffn2p).  x_out may alias x.
+// Fused feed-forward block: x_out = x + W2 relu(W1 n(x) + b1) + b2, and optionally y = n(x_out) as 16-bit, where
+// n(.) normalises a row to zero mean and unit variance (the LayerNorm scale and shift live in the weights).
+// x_out may alias x.
 struct FfnParams {
     const float* x;        // [M][512]
     float* x_out;          // [M][512]
-    const float* ln_g;     // LayerNorm in front of the block (norm2)
-    const float* ln_b;
-    const uint16_t* w1;    // [ff][512], columns permuted
+    const uint16_t* wstream;  // W1 and W2 as the kernel's piece stream (LayerWeights::w_ffn_stream)
     const float* b1;       // [ff]
-    const uint16_t* w2;    // [512][ff], columns permuted
     const float* b2;       // [512]
     void* y;               // optional 16-bit [M][ldy] in the compute dtype
     int ldy;
-    const float* y_g;      // LayerNorm applied to x_out for y (the next layer's norm1)
-    const float* y_b;
     float eps;
     int M, ff;
+    int flags;             // timing experiments only (results are wrong): bit 0 skip the stores, bit 1 skip the weight
+                           // staging (builds with -DASRFE_FFN_TIMING=1 only)
 };
 int32_t launch_ffn(asrfe_ctx* ctx, const FfnParams& p, hipStream_t s);
 

@@ -88,8 +88,11 @@ __global__ __launch_bounds__(256) void ln_kernel(const LnParams p) {
         const int idx = lane + 64 * k;
         float4 y = make_float4(0.f, 0.f, 0.f, 0.f);
         if (idx < nvec && live) {
-            const float4 g = reinterpret_cast<const float4*>(p.g)[idx];
-            const float4 bb = reinterpret_cast<const float4*>(p.b)[idx];
+            float4 g = make_float4(1.f, 1.f, 1.f, 1.f), bb = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (p.g) {  // null: the scale and shift are folded into the linear layer that follows
+                g = reinterpret_cast<const float4*>(p.g)[idx];
+                bb = reinterpret_cast<const float4*>(p.b)[idx];
+            }
             y.x = (v[k].x - mean) * rstd * g.x + bb.x;
             y.y = (v[k].y - mean) * rstd * g.y + bb.y;
             y.z = (v[k].z - mean) * rstd * g.z + bb.z;

@@ -1,15 +1,17 @@
 // Fused position-wise feed-forward block of one SAN-M encoder layer on gfx950:
 //
-//     x_out = x + W2 relu(W1 LN(x) + b1) + b2            (fp32 residual stream, 512 columns)
-//     y     = LN'(x_out)  as 16-bit                       (optional: the next layer's norm1)
+//     x_out = x + W2 relu(W1 n(x) + b1) + b2             (fp32 residual stream, 512 columns)
+//     y     = n(x_out)  as 16-bit                          (optional: the next layer's normalised input)
+// n(.) normalises a row to zero mean and unit variance; the scale and shift of the two LayerNorms are folded
+// into W1 / b1 and into the next layer's QKV projection when the weights are loaded.
 //
 // One workgroup = 128 rows of x, 4 waves, ONE wave per SIMD so that a wave may use the whole 512-entry
 // register file.  A wave owns 32 complete rows for the whole kernel:
 //   - the 32 x 512 fp32 output tile is 16 accumulators of v_mfma_f32_32x32x16 (256 registers) which start
 //     as x + b2, so the residual never leaves registers;
-//   - LN(x) is computed inside the wave (a row lives in the two lanes l and l + 32) and kept as the 32
+//   - n(x) is computed inside the wave (a row lives in the two lanes l and l + 32) and kept as the 32
 //     MFMA operand fragments of the first GEMM (128 registers);
-//   - the hidden layer is produced 64 units at a time: H^T[64][32] = W1_chunk LN(x)^T (2 accumulators),
+//   - the hidden layer is produced 64 units at a time: H^T[64][32] = W1_chunk n(x)^T (2 accumulators),
 //     ReLU + rounding turn it straight into the operand fragments of the second GEMM, which adds
 //     W2[:, chunk] H^T into the output tile.  The 2048-wide intermediate never exists in memory.
 //
@@ -22,8 +24,9 @@
 // Weights stream through LDS as 16 KiB pieces, 8 per chunk of 64 hidden units:
 //     pieces 0..3 : W1[chunk rows 64][128 k]    (256-byte rows, 16-byte slot c of row r holds chunk c ^ (r & 15))
 //     pieces 4..7 : W2[128 n][chunk cols 64]    (128-byte rows, slot c of row r holds chunk c ^ ((r >> 1) & 7))
-// filled by 16-byte LDS-DMA loads with the swizzle applied to the source address.  Piece r of every chunk
-// uses ring slot r.  A wave issues 16 MFMAs per piece; the fragment for MFMA i + 8 is read right after
+// The host stores both matrices as the stream of these images in consumption order
+// (asrfe_load_encoder_weights), so a piece is 16 KiB of contiguous memory copied by 16-byte LDS-DMA loads.
+// Piece r of every chunk uses ring slot r.  A wave issues 16 MFMAs per piece; the fragment for MFMA i + 8 is read right after
 // MFMA i, so in the middle of piece q the wave needs piece q + 1: there it waits (counted vmcnt: five
 // younger pieces stay in flight), meets the other waves at one s_barrier, and then refills the slot of
 // piece q - 1, whose last read every wave finished before that barrier.
@@ -35,20 +38,24 @@
 
 namespace asrfe {
 
+#ifndef ASRFE_FFN_TIMING
+#define ASRFE_FFN_TIMING 0
+#endif
+
 constexpr int kFfnThreads = 256;
 constexpr int kFfnRows = 128;
 constexpr int kPieceBytes = 16384;
-constexpr int kFfnRing = 8 * kPieceBytes;  // 128 KiB; the fp32 b1 vector follows it
+constexpr int kFfnRing = 8 * kPieceBytes;  // 128 KiB; the fp32 b1 and b2 vectors follow it
 
-// 16-byte LDS-DMA load: LDS[m0 + 16 * lane] = *gptr.  Issued through inline assembly on purpose: the compiler
+// 16-byte LDS-DMA load: LDS[m0 + 16 * lane] = *(sbase + voff) (scalar base, 32-bit per-lane offset).  Issued through inline assembly on purpose: the compiler
 // models a load that touches both global memory and LDS as a flat access and, while one is pending, turns
 // every wait it inserts into vmcnt(0) / lgkmcnt(0); hidden from it, its LDS-read waits stay counted.  The
 // kernel orders these loads itself (wait_vm_barrier).
-__device__ __forceinline__ void ffn_glds16(const void* gptr, uint32_t lds_addr) {
-    asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(lds_addr), "v"(gptr) : "memory");
+__device__ __forceinline__ void ffn_glds16(const void* sbase, uint32_t voff, uint32_t lds_addr) {
+    asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(lds_addr), "v"(voff), "s"(sbase) : "memory");
 }
 __device__ __forceinline__ uint32_t lds_addr_of(const void* p) {
-    return static_cast<uint32_t>(reinterpret_cast<uintptr_t>(p));  // low half of a generic LDS pointer = LDS offset
+    return static_cast<uint32_t>(reinterpret_cast<uintptr_t>((const __attribute__((address_space(3))) char*)p));
 }
 
 template <int I>
@@ -103,6 +110,37 @@ __device__ __forceinline__ void tile_in(f32x16& acc, const f32x16 t) {
     asm volatile("" : "+a"(acc));
 }
 
+// Running mean and sum of squared deviations of N values merged with one more tile of 16 (pairwise update of
+// Chan et al.): one pass over the data with the accuracy of the two-pass form.
+__device__ __forceinline__ void stat_merge_tile(float& mean, float& m2, const int N, const f32x16& t) {
+    float s = 0.0f;
+#pragma unroll
+    for (int e = 0; e < 16; e += 4) s += (t[e] + t[e + 1]) + (t[e + 2] + t[e + 3]);
+    const float mt = s * (1.0f / 16.0f);
+    float q = 0.0f;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        const float d = t[e] - mt;
+        q += d * d;
+    }
+    if (N == 0) {  // N is a constant after unrolling
+        mean = mt;
+        m2 = q;
+    } else {
+        const float d = mt - mean;
+        mean += d * (16.0f / static_cast<float>(N + 16));
+        m2 += q + d * d * (16.0f * static_cast<float>(N) / static_cast<float>(N + 16));
+    }
+}
+// the two lanes of a row (256 values each) -> mean and 1 / sqrt(var + eps) of the 512
+__device__ __forceinline__ void stat_finish_row(float& mean, float m2, float eps, float& rstd) {
+    const float mo = __shfl_xor(mean, 32), qo = __shfl_xor(m2, 32);
+    const float d = mo - mean;
+    m2 = m2 + qo + d * d * 128.0f;
+    mean = 0.5f * (mean + mo);
+    rstd = 1.0f / sqrtf(m2 * (1.0f / 512.0f) + eps);
+}
+
 __device__ __forceinline__ float relu(float v) { return __builtin_amdgcn_fmed3f(v, 0.0f, __builtin_inff()); }
 
 template <bool F16>
@@ -121,68 +159,90 @@ __global__ __launch_bounds__(kFfnThreads) void ffn_kernel(const FfnParams p) {
     const int l31 = lane & 31, h = lane >> 5;
     const int row0 = blockIdx.x * kFfnRows + wave * 32;
     const int nch = p.ff >> 6;
-    const uint32_t ffb = static_cast<uint32_t>(p.ff) * 2;  // bytes per row of W2
     float* b1s = reinterpret_cast<float*>(smem + kFfnRing);
 
-    // ---- staging: thread covers 16-byte LDS slot (i * 256 + tid) of a piece, i = 0..3
-    const char* w1 = reinterpret_cast<const char*>(p.w1);
-    const char* w2 = reinterpret_cast<const char*>(p.w2);
-    const uint32_t g1off = static_cast<uint32_t>(tid >> 4) * 1024u + (((tid & 15) ^ ((tid >> 4) & 15)) << 4);
-    const uint32_t g2off = static_cast<uint32_t>(tid >> 3) * ffb + (((tid & 7) ^ ((tid >> 4) & 7)) << 4);
+    // ---- staging: the weights arrive as a stream of ready-made 16 KiB LDS images (piece 8 j + r of chunk j), so a
+    //      wave copies four contiguous 1 KiB runs per piece
+    const char* wsrc = reinterpret_cast<const char*>(p.wstream);
+    const uint32_t wlane = wave * 1024 + lane * 16;
     const uint32_t smem_base = __builtin_amdgcn_readfirstlane(lds_addr_of(smem));
-    auto stage = [&](auto rc, int j) {
+    // timing experiments only (bit 1 needs a build with -DASRFE_FFN_TIMING=1: the test costs issue slots)
+    const bool no_store = p.flags & 1;
+    [[maybe_unused]] const bool no_stage = p.flags & 2;
+    // quarter i (4 KiB: one 1 KiB run per wave) of piece R of the chunk whose eight pieces start at cbase
+    auto stage_quarter = [&](auto rc, const char* cbase, int i) {
         constexpr int R = decltype(rc)::value;
+#if ASRFE_FFN_TIMING
+        if (no_stage) return;
+#endif
         const uint32_t dst = __builtin_amdgcn_readfirstlane(smem_base + R * kPieceBytes + wave * 1024);
-        if constexpr (R < 4) {
-            const char* src = w1 + static_cast<uint32_t>(j) * 65536u + R * 256 + g1off;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) ffn_glds16(src + i * 16384, dst + i * 4096);
-        } else {
-            const char* src = w2 + static_cast<uint32_t>(R - 4) * 128u * ffb + static_cast<uint32_t>(j) * 128u + g2off;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) ffn_glds16(src + static_cast<uint32_t>(i) * 32u * ffb, dst + i * 4096);
-        }
+        ffn_glds16(cbase + R * kPieceBytes + i * 4096, wlane, dst + i * 4096);
     };
-    // the first seven pieces fly while x is loaded and normalised
-    stage(IC<0>{}, 0); stage(IC<1>{}, 0); stage(IC<2>{}, 0); stage(IC<3>{}, 0);
-    stage(IC<4>{}, 0); stage(IC<5>{}, 0); stage(IC<6>{}, 0);
+    auto chunk_base = [&](int j) { return wsrc + static_cast<int64_t>(j) * (8 * kPieceBytes); };
+    auto stage = [&](auto rc, const char* cbase) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) stage_quarter(rc, cbase, i);
+    };
+    // the first four pieces fly while x is loaded and normalised; slots 4..7 serve as x staging until then
+    const char* cb_first = chunk_base(0);
+    stage(IC<0>{}, cb_first); stage(IC<1>{}, cb_first); stage(IC<2>{}, cb_first); stage(IC<3>{}, cb_first);
 
     for (int i = tid * 4; i < p.ff; i += kFfnThreads * 4)
         *reinterpret_cast<float4*>(b1s + i) = *reinterpret_cast<const float4*>(p.b1 + i);
+    float* b2s = b1s + p.ff;  // both bias vectors live in LDS: a global load per use would be waited for one by one
+    if (tid < 128) *reinterpret_cast<float4*>(b2s + tid * 4) = *reinterpret_cast<const float4*>(p.b2 + tid * 4);
 
     // ---- x in accumulator layout: register 4 g + e of tile nt is column 32 nt + 8 g + 4 h + e of row l31.
-    //      Three passes, one 32-column tile in working registers at a time (tile_in / tile_out pin the moves).
-    const int mrow = min(row0 + l31, p.M - 1);
-    const float* xrow = p.x + static_cast<int64_t>(mrow) * 512 + 4 * h;
+    //      x also comes in by LDS-DMA (no staging registers): a 32-row x 32-column tile is a 4 KiB slab of 128-byte
+    //      rows, 16-byte slot c of row r holding chunk c ^ (r & 7), filled by four loads whose per-lane source
+    //      addresses carry the swizzle.  Every wave owns ring slot 4 + wave as four such slabs, refilled as they are
+    //      consumed, so three tiles are always in flight.  Two passes over the tile registers follow, one tile in
+    //      working registers at a time (tile_in / tile_out pin the moves).
     f32x16 oacc[16];
-    u16x8 afrag[32];  // LN(x) as operand fragments: afrag[2 nt + q] = registers 8 q .. 8 q + 7 of tile nt
+    u16x8 afrag[32];  // n(x) as operand fragments: afrag[2 nt + q] = registers 8 q .. 8 q + 7 of tile nt
     {
-        float s = 0.0f;
+        const uint32_t xs_lds = __builtin_amdgcn_readfirstlane(smem_base + (4 + wave) * kPieceBytes);
+        const char* xs = smem + (4 + wave) * kPieceBytes;
+        // the per-lane offset is an UNSIGNED 32-bit addend of the scalar base, so the base is the wave's first valid
+        // row and rows past M - 1 re-read row M - 1 (never a negative offset)
+        const int rbase = min(row0, p.M - 1);
+        const char* xsrc = reinterpret_cast<const char*>(p.x) + static_cast<int64_t>(rbase) * 2048;
+        uint32_t xoff[4];  // lane's source offset for rows 8 k + (lane >> 3)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int r = 8 * k + (lane >> 3);
+            const int rr = min(row0 + r, p.M - 1) - rbase;
+            xoff[k] = static_cast<uint32_t>(rr * 2048 + (((lane & 7) ^ (r & 7)) << 4));
+        }
+        auto x_tile_dma = [&](int nt) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) ffn_glds16(xsrc + nt * 128, xoff[k], xs_lds + (nt & 3) * 4096 + k * 1024);
+        };
+        x_tile_dma(0); x_tile_dma(1); x_tile_dma(2); x_tile_dma(3);
+        float mean = 0.0f, m2 = 0.0f, rstd;
 #pragma unroll
         for (int nt = 0; nt < 16; ++nt) {
+            // tile nt has landed once at most the loads of the tiles behind it are outstanding (in-order counter)
+            if (nt <= 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+            else if (nt == 13) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else if (nt == 14) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             f32x16 t;
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                const float4 u = *reinterpret_cast<const float4*>(xrow + 32 * nt + 8 * g);
-                t[4 * g] = u.x; t[4 * g + 1] = u.y; t[4 * g + 2] = u.z; t[4 * g + 3] = u.w;
-                s += (u.x + u.y) + (u.z + u.w);
+                const float4 v = *reinterpret_cast<const float4*>(xs + (nt & 3) * 4096 + l31 * 128 + (((2 * g + h) ^ (l31 & 7)) << 4));
+                t[4 * g] = v.x; t[4 * g + 1] = v.y; t[4 * g + 2] = v.z; t[4 * g + 3] = v.w;
             }
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(t) : : "memory");  // the slab is read before it is refilled
+            if (nt + 4 < 16) x_tile_dma(nt + 4);
+            stat_merge_tile(mean, m2, 16 * nt, t);
             tile_in(oacc[nt], t);
         }
-        s += __shfl_xor(s, 32);
-        const float mean = s * (1.0f / 512.0f);
-        float sq = 0.0f;
-#pragma unroll
-        for (int nt = 0; nt < 16; ++nt) {
-            const f32x16 t = tile_out(oacc[nt]);
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const float dlt = t[e] - mean;
-                sq += dlt * dlt;
-            }
-        }
-        sq += __shfl_xor(sq, 32);
-        const float rstd = 1.0f / sqrtf(sq * (1.0f / 512.0f) + p.eps);
+        // every wave is done with its x slabs: slots 4..6 can take their weight pieces
+        __syncthreads();
+        stage(IC<4>{}, cb_first); stage(IC<5>{}, cb_first); stage(IC<6>{}, cb_first);
+        stat_finish_row(mean, m2, p.eps, rstd);
+        const float shift = -mean * rstd;
 #pragma unroll
         for (int nt = 0; nt < 16; ++nt) {
             f32x16 t = tile_out(oacc[nt]);
@@ -191,20 +251,17 @@ __global__ __launch_bounds__(kFfnThreads) void ffn_kernel(const FfnParams p) {
                 float v[8];
 #pragma unroll
                 for (int gg = 0; gg < 2; ++gg) {
-                    const int col = 32 * nt + 8 * (2 * q + gg) + 4 * h;
-                    const float4 gm = *reinterpret_cast<const float4*>(p.ln_g + col);
-                    const float4 bt = *reinterpret_cast<const float4*>(p.ln_b + col);
-                    v[4 * gg + 0] = (t[8 * q + 4 * gg + 0] - mean) * rstd * gm.x + bt.x;
-                    v[4 * gg + 1] = (t[8 * q + 4 * gg + 1] - mean) * rstd * gm.y + bt.y;
-                    v[4 * gg + 2] = (t[8 * q + 4 * gg + 2] - mean) * rstd * gm.z + bt.z;
-                    v[4 * gg + 3] = (t[8 * q + 4 * gg + 3] - mean) * rstd * gm.w + bt.w;
+                    v[4 * gg + 0] = t[8 * q + 4 * gg + 0] * rstd + shift;
+                    v[4 * gg + 1] = t[8 * q + 4 * gg + 1] * rstd + shift;
+                    v[4 * gg + 2] = t[8 * q + 4 * gg + 2] * rstd + shift;
+                    v[4 * gg + 3] = t[8 * q + 4 * gg + 3] * rstd + shift;
                 }
                 afrag[2 * nt + q] = pack8<F16>(v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7]);
             }
             // the output tile starts as x + b2
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                const float4 u = *reinterpret_cast<const float4*>(p.b2 + 32 * nt + 8 * g + 4 * h);
+                const float4 u = *reinterpret_cast<const float4*>(b2s + 32 * nt + 8 * g + 4 * h);
                 t[4 * g] += u.x; t[4 * g + 1] += u.y; t[4 * g + 2] += u.z; t[4 * g + 3] += u.w;
             }
             tile_in(oacc[nt], t);
@@ -248,7 +305,7 @@ __global__ __launch_bounds__(kFfnThreads) void ffn_kernel(const FfnParams p) {
         }
     };
     // piece R of chunk j; LAST: j is the final chunk (nothing further to stage)
-    auto step = [&](auto rc, int j, auto lastc) {
+    auto step = [&](auto rc, int j, const char* cb0, const char* cb1, auto lastc) {
         constexpr int R = decltype(rc)::value;
         constexpr bool LAST = decltype(lastc)::value;
         static_for<8>([&](auto f) {
@@ -256,14 +313,10 @@ __global__ __launch_bounds__(kFfnThreads) void ffn_kernel(const FfnParams p) {
             mma(rc, f);
             wf[F] = frag(rc, IC<F + 8>{});
         });
-        if constexpr (!LAST) {
-            wait_vm_barrier<20>();
-            if constexpr (R == 0) stage(IC<7>{}, j);
-            else stage(IC<(R + 7) & 7>{}, j + 1);
-        } else {
-            wait_vm_barrier<(R <= 1 ? 20 : (R <= 6 ? 4 * (6 - R) : 0))>();
-            if constexpr (R == 0) stage(IC<7>{}, j);
-        }
+        // An LDS-DMA instruction holds the wave's issue for tens of cycles, so the four of a piece are spread
+        // over the MFMA gaps of the second half instead of being issued back to back.
+        if constexpr (!LAST) wait_vm_barrier<20>();
+        else wait_vm_barrier<(R <= 1 ? 20 : (R <= 6 ? 4 * (6 - R) : 0))>();
         // the hidden-chunk accumulators are idle from the ReLU to the end of the chunk: reload them with the next
         // chunk's bias here, eight MFMAs ahead of their first use
         if constexpr (R == 7 && !LAST) init_acc1(j + 1);
@@ -271,13 +324,20 @@ __global__ __launch_bounds__(kFfnThreads) void ffn_kernel(const FfnParams p) {
             constexpr int F = decltype(f)::value;
             mma(rc, IC<F + 8>{});
             if constexpr (!(LAST && R == 7)) wf[F] = frag(IC<((R + 1) & 7)>{}, f);
+            if constexpr ((F & 1) == 0) {
+                if constexpr (R == 0) stage_quarter(IC<7>{}, cb0, F >> 1);
+                else if constexpr (!LAST) stage_quarter(IC<(R + 7) & 7>{}, cb1, F >> 1);
+            }
         });
     };
     auto chunk = [&](int j, auto lastc) {
-        step(IC<0>{}, j, lastc);
-        step(IC<1>{}, j, lastc);
-        step(IC<2>{}, j, lastc);
-        step(IC<3>{}, j, lastc);
+        // this chunk's and the next chunk's pieces in the weight stream (uniform: scalar registers)
+        const char* cb0 = chunk_base(j);
+        const char* cb1 = chunk_base(j + 1);
+        step(IC<0>{}, j, cb0, cb1, lastc);
+        step(IC<1>{}, j, cb0, cb1, lastc);
+        step(IC<2>{}, j, cb0, cb1, lastc);
+        step(IC<3>{}, j, cb0, cb1, lastc);
         // The compiler does not see inside the asm MFMAs, so the wait states between an MFMA and a VALU read of
         // its result are covered by hand; the nops are tied to both tiles so that no read can move above them.
         asm volatile("s_nop 15\n\ts_nop 7" : "+v"(acc1[0]), "+v"(acc1[1]));
@@ -288,10 +348,10 @@ __global__ __launch_bounds__(kFfnThreads) void ffn_kernel(const FfnParams p) {
             hp[kk] = pack8<F16>(relu(a[o]), relu(a[o + 1]), relu(a[o + 2]), relu(a[o + 3]), relu(a[o + 4]), relu(a[o + 5]),
                                 relu(a[o + 6]), relu(a[o + 7]));
         }
-        step(IC<4>{}, j, lastc);
-        step(IC<5>{}, j, lastc);
-        step(IC<6>{}, j, lastc);
-        step(IC<7>{}, j, lastc);
+        step(IC<4>{}, j, cb0, cb1, lastc);
+        step(IC<5>{}, j, cb0, cb1, lastc);
+        step(IC<6>{}, j, cb0, cb1, lastc);
+        step(IC<7>{}, j, cb0, cb1, lastc);
     };
 
     __syncthreads();  // b1 is in LDS
@@ -309,30 +369,19 @@ __global__ __launch_bounds__(kFfnThreads) void ffn_kernel(const FfnParams p) {
     char* ys = es + 4096;           // 16-bit slab of y
     const int wr_row = l31 * 128, wr_sw = l31 & 7;
     const int rd_row = lane >> 3, rd_c = lane & 7;
-    float mean = 0.0f, rstd = 0.0f;
+    float mean = 0.0f, m2 = 0.0f, rstd = 0.0f, shift = 0.0f;
     if constexpr (HAS_Y) {
-        float s = 0.0f;
+        // pass 1: row statistics of x_out
 #pragma unroll
         for (int nt = 0; nt < 16; ++nt) {
             const f32x16 t = tile_out(oacc[nt]);
-#pragma unroll
-            for (int e = 0; e < 16; e += 4) s += (t[e] + t[e + 1]) + (t[e + 2] + t[e + 3]);
+            stat_merge_tile(mean, m2, 16 * nt, t);
         }
-        s += __shfl_xor(s, 32);
-        mean = s * (1.0f / 512.0f);
-        float sq = 0.0f;
-#pragma unroll
-        for (int nt = 0; nt < 16; ++nt) {
-            const f32x16 t = tile_out(oacc[nt]);
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const float dlt = t[e] - mean;
-                sq += dlt * dlt;
-            }
-        }
-        sq += __shfl_xor(sq, 32);
-        rstd = 1.0f / sqrtf(sq * (1.0f / 512.0f) + p.eps);
+        stat_finish_row(mean, m2, p.eps, rstd);
+        shift = -mean * rstd;
     }
+    // pass 2: x_out and, from the same registers, y = the normalised rows rounded to 16 bits (two tiles make one
+    // 128-byte row piece of y)
 #pragma unroll
     for (int nt = 0; nt < 16; ++nt) {
         const f32x16 t = tile_out(oacc[nt]);
@@ -346,26 +395,17 @@ __global__ __launch_bounds__(kFfnThreads) void ffn_kernel(const FfnParams p) {
             const int r = rd_row + 8 * i;
             const float4 v = *reinterpret_cast<const float4*>(es + r * 128 + ((rd_c ^ (r & 7)) << 4));
             const int m = row0 + r;
-            if (m < p.M) *reinterpret_cast<float4*>(p.x_out + static_cast<int64_t>(m) * 512 + 32 * nt + rd_c * 4) = v;
+            if (m < p.M && !no_store) *reinterpret_cast<float4*>(p.x_out + static_cast<int64_t>(m) * 512 + 32 * nt + rd_c * 4) = v;
         }
         ffn_wave_lds_sync();
         if constexpr (HAS_Y) {
-            // the same tile, normalised and rounded: half of a 128-byte row piece of y (64 columns per pair of tiles)
             uint16_t* y = reinterpret_cast<uint16_t*>(p.y);
             const int ns = nt & 1;
 #pragma unroll
             for (int gp = 0; gp < 2; ++gp) {
                 float v[8];
 #pragma unroll
-                for (int gg = 0; gg < 2; ++gg) {
-                    const int col = 32 * nt + 16 * gp + 8 * gg + 4 * h;
-                    const float4 gm = *reinterpret_cast<const float4*>(p.y_g + col);
-                    const float4 bt = *reinterpret_cast<const float4*>(p.y_b + col);
-                    v[4 * gg + 0] = (t[8 * gp + 4 * gg + 0] - mean) * rstd * gm.x + bt.x;
-                    v[4 * gg + 1] = (t[8 * gp + 4 * gg + 1] - mean) * rstd * gm.y + bt.y;
-                    v[4 * gg + 2] = (t[8 * gp + 4 * gg + 2] - mean) * rstd * gm.z + bt.z;
-                    v[4 * gg + 3] = (t[8 * gp + 4 * gg + 3] - mean) * rstd * gm.w + bt.w;
-                }
+                for (int e = 0; e < 8; ++e) v[e] = t[8 * gp + e] * rstd + shift;
                 const uint32_t lo0 = pack_elem2<F16>(v[0], v[1]), lo1 = pack_elem2<F16>(v[2], v[3]);
                 const uint32_t hi0 = pack_elem2<F16>(v[4], v[5]), hi1 = pack_elem2<F16>(v[6], v[7]);
                 // lanes 32..63 of lo swap with lanes 0..31 of hi: h = 0 ends with columns 0..7 of the 16, h = 1 with 8..15
@@ -381,7 +421,7 @@ __global__ __launch_bounds__(kFfnThreads) void ffn_kernel(const FfnParams p) {
                     const int r = rd_row + 8 * i;
                     const uint4 v = *reinterpret_cast<const uint4*>(ys + r * 128 + ((rd_c ^ (r & 7)) << 4));
                     const int m = row0 + r;
-                    if (m < p.M) *reinterpret_cast<uint4*>(y + static_cast<int64_t>(m) * p.ldy + 32 * (nt - 1) + rd_c * 8) = v;
+                    if (m < p.M && !no_store) *reinterpret_cast<uint4*>(y + static_cast<int64_t>(m) * p.ldy + 32 * (nt - 1) + rd_c * 8) = v;
                 }
                 ffn_wave_lds_sync();
             }
@@ -391,29 +431,32 @@ __global__ __launch_bounds__(kFfnThreads) void ffn_kernel(const FfnParams p) {
 
 int32_t launch_ffn(asrfe_ctx* ctx, const FfnParams& p, hipStream_t s) {
     if (p.M <= 0) return ASRFE_OK;
-    if (p.ff < 64 || p.ff % 64 != 0 || p.ff > 8192)
-        return set_err(ctx, ASRFE_ERR_SHAPE, "ffn: linear_units must be a multiple of 64 in 64..8192");
-    if (!p.x || !p.x_out || !p.w1 || !p.w2 || !p.b1 || !p.b2 || !p.ln_g || !p.ln_b || (p.y && (!p.y_g || !p.y_b || p.ldy % 8 != 0)))
+    if (p.ff < 64 || p.ff % 64 != 0 || p.ff > 7680)
+        return set_err(ctx, ASRFE_ERR_SHAPE, "ffn: linear_units must be a multiple of 64 in 64..7680");
+    if (!p.x || !p.x_out || !p.wstream || !p.b1 || !p.b2 || (p.y && p.ldy % 8 != 0))
         return set_err(ctx, ASRFE_ERR_BAD_ARG, "ffn: null or misaligned argument");
-    const int lds = kFfnRing + p.ff * 4;
-    static bool attr_done = false;
-    if (!attr_done) {
-        const void* fns[4] = {reinterpret_cast<const void*>(ffn_kernel<false, false>), reinterpret_cast<const void*>(ffn_kernel<false, true>),
-                              reinterpret_cast<const void*>(ffn_kernel<true, false>), reinterpret_cast<const void*>(ffn_kernel<true, true>)};
-        for (const void* f : fns)
-            if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
-                return set_err(ctx, ASRFE_ERR_HIP, "ffn: cannot raise the dynamic LDS limit to 160 KiB");
-        attr_done = true;
-    }
+    const int lds = kFfnRing + p.ff * 4 + 512 * 4;
     const dim3 grid((p.M + kFfnRows - 1) / kFfnRows), block(kFfnThreads);
     const bool f16 = ctx->cfg.enc_compute_dtype == ASRFE_DT_F16;
+#define FFN_LAUNCH(F, Y)                                                                                        \
+    do {                                                                                                        \
+        static bool attr_done = false;                                                                          \
+        if (!attr_done) {                                                                                       \
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(ffn_kernel<F, Y>),                         \
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)      \
+                return set_err(ctx, ASRFE_ERR_HIP, "ffn: cannot raise the dynamic LDS limit to 160 KiB");       \
+            attr_done = true;                                                                                   \
+        }                                                                                                       \
+        hipLaunchKernelGGL((ffn_kernel<F, Y>), grid, block, lds, s, p);                                      \
+    } while (0)
     if (f16) {
-        if (p.y) hipLaunchKernelGGL((ffn_kernel<true, true>), grid, block, lds, s, p);
-        else hipLaunchKernelGGL((ffn_kernel<true, false>), grid, block, lds, s, p);
+        if (p.y) FFN_LAUNCH(true, true);
+        else FFN_LAUNCH(true, false);
     } else {
-        if (p.y) hipLaunchKernelGGL((ffn_kernel<false, true>), grid, block, lds, s, p);
-        else hipLaunchKernelGGL((ffn_kernel<false, false>), grid, block, lds, s, p);
+        if (p.y) FFN_LAUNCH(false, true);
+        else FFN_LAUNCH(false, false);
     }
+#undef FFN_LAUNCH
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) return set_err(ctx, ASRFE_ERR_HIP, std::string("ffn launch: ") + hipGetErrorString(e));
     return ASRFE_OK;

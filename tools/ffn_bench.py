@@ -1,0 +1,101 @@
+#!/usr/bin/env python3
+"""Times and checks the fused feed-forward kernel in isolation (through asrfe_debug_ffn).
+
+    python tools/ffn_bench.py [--check] [--iters 30] [--flags 0 1 2 ...]
+"""
+import argparse
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import toolbox_for_asr_and_tts_amd as pkg  # noqa: E402
+from toolbox_for_asr_and_tts_amd.synth import encoder_state_dict  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--check", action="store_true")
+    ap.add_argument("--iters", type=int, default=30)
+    ap.add_argument("--rows", type=int, default=32000)
+    ap.add_argument("--repeat", type=int, default=2)
+    ap.add_argument("--flags", type=int, nargs="*", default=[0])
+    args = ap.parse_args()
+    enc = pkg.SANMEncoder(num_blocks=2)
+    sd = encoder_state_dict(num_blocks=2, seed=3)
+    gen = torch.Generator().manual_seed(5)
+    for k in sd:  # non-trivial LayerNorm parameters and biases, so that a column mix-up shows
+        if "norm" in k or k.endswith(".bias"):
+            sd[k] = sd[k] + 0.1 * torch.randn(sd[k].shape, generator=gen)
+    enc.load_state_dict(sd)
+    ctx, lib = enc.ctx, enc.ctx.lib
+    dev = "cuda"
+    stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    if args.check:
+        for m in (1, 33, 128, 1000):
+            x = torch.randn(m, 512, device=dev) * 2.0 + 0.3
+            xo = torch.empty_like(x)
+            y = torch.empty(m, 512, device=dev, dtype=torch.float16)
+            ctx.check(lib.asrfe_debug_ffn(ctx.handle, 0, x.data_ptr(), xo.data_ptr(), y.data_ptr(), m, 0, stream))
+            g = {k: v.to(dev).float() for k, v in sd.items()}
+            pfx = "encoders0.0."
+            h = torch.nn.functional.layer_norm(x, (512,), g[pfx + "norm2.weight"], g[pfx + "norm2.bias"], 1e-12)
+            h = torch.relu(h.half().float() @ g[pfx + "feed_forward.w_1.weight"].half().float().T + g[pfx + "feed_forward.w_1.bias"])
+            ref = x + h.half().float() @ g[pfx + "feed_forward.w_2.weight"].half().float().T + g[pfx + "feed_forward.w_2.bias"]
+            yref = torch.nn.functional.layer_norm(ref, (512,), None, None, 1e-12)  # scale / shift live in the next QKV
+            e1 = (xo - ref).abs().max().item()
+            e2 = (y.float() - yref).abs().max().item()
+            print(f"check m={m}: x_out err {e1:.3e}, y err {e2:.3e}")
+            assert e1 < 2e-3 and e2 < 1e-2
+    m = args.rows
+    x = torch.randn(m, 512, device=dev)
+    y = torch.empty(m, 512, device=dev, dtype=torch.float16)
+    import time
+    t0 = time.time()
+    while time.time() - t0 < 1.5:  # let the clocks settle before the first measurement
+        for _ in range(50):
+            ctx.check(lib.asrfe_debug_ffn(ctx.handle, 0, x.data_ptr(), x.data_ptr(), y.data_ptr(), m, 0, stream))
+        x.normal_()
+        torch.cuda.synchronize()
+    # clock reference: boxes differ by up to ~10 %, so every run also times the plain GEMM (FFN1 shape)
+    ga = (torch.randn(m, 512, device=dev) * 0.5).half()
+    gw = (torch.randn(2048, 512, device=dev) * 0.05).half()
+    gb = torch.randn(2048, device=dev)
+    go = torch.empty(m, 2048, device=dev, dtype=torch.float16)
+
+    def ref_gemm():
+        for _ in range(10):
+            ctx.check(lib.asrfe_debug_gemm(ctx.handle, ga.data_ptr(), 512, gw.data_ptr(), 512, gb.data_ptr(), m, 2048, 512,
+                                           go.data_ptr(), 2048, None, None, 1, 0, stream))
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(args.iters):
+            ctx.check(lib.asrfe_debug_gemm(ctx.handle, ga.data_ptr(), 512, gw.data_ptr(), 512, gb.data_ptr(), m, 2048, 512,
+                                           go.data_ptr(), 2048, None, None, 1, 0, stream))
+        e1.record()
+        torch.cuda.synchronize()
+        print(f"reference gemm [{m} x 512] x [512 x 2048]: {1e3 * e0.elapsed_time(e1) / args.iters:7.1f} us")
+
+    ref_gemm()
+    for flags in args.flags * args.repeat:
+        def run():
+            ctx.check(lib.asrfe_debug_ffn(ctx.handle, 0, x.data_ptr(), x.data_ptr(), y.data_ptr(), m, flags, stream))
+        x.normal_()
+        for _ in range(3):
+            run()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(args.iters):
+            run()
+        e1.record()
+        torch.cuda.synchronize()
+        us = 1e3 * e0.elapsed_time(e1) / args.iters
+        print(f"ffn M={m} flags={flags}: {us:7.1f} us  {2.0 * m * 2048 * 512 * 2 / us / 1e6:7.1f} TFLOP/s")
+    ref_gemm()
+
+
+if __name__ == "__main__":
+    main()
