@@ -155,7 +155,7 @@ typedef struct asrfe_profile {
     float total_ms[ASRFE_PROF_KINDS];
 } asrfe_profile;
 /* kinds: 0 fbank, 1 frontend(fused), 2 lfr_cmvn, 3 pe_table, 4 layernorm, 5 gemm_qkv, 6 fsmn,
- *        7 attention, 8 gemm_out, 9 gemm_ffn1, 10 gemm_ffn2, 11 ffn_fused (norm2 + both linears + next norm1) */
+ *        7 attention, 8 gemm_out, 9 gemm_ffn1, 10 gemm_ffn2, 11 post_attn (output projection + FSMN + residual, norm2, feed-forward, next norm1) */
 int32_t asrfe_profile_begin(asrfe_ctx* ctx, int32_t max_launches);
 int32_t asrfe_profile_end(asrfe_ctx* ctx, asrfe_profile* out);
 
@@ -168,12 +168,14 @@ int32_t asrfe_debug_gemm(asrfe_ctx* ctx, const void* a, int32_t lda, const void*
                          int32_t m, int32_t n, int32_t k, void* out, int32_t ldo, const void* add16,
                          const float* add32, int32_t epi, int32_t flags, void* stream);
 
-/* Kernel-level test hook (no counterpart in the reference): one launch of the fused feed-forward kernel of
- * encoder layer `layer` on x [m][512] float32:  x_out = x + W2 relu(W1 norm2(x) + b1) + b2 (x_out may alias x) and,
- * when y is not NULL, y [m][512] = LayerNorm(x_out) in the 16-bit compute dtype with the next layer's norm1
- * parameters (after_norm's for the last layer).  flags != 0 are timing experiments that produce wrong results. */
-int32_t asrfe_debug_ffn(asrfe_ctx* ctx, int32_t layer, const float* x, float* x_out, void* y, int32_t m,
-                        int32_t flags, void* stream);
+/* Kernel-level test hook (no counterpart in the reference): one launch of the fused post-attention kernel of
+ * encoder layer `layer` on m rows: att, fsmn [m][512] in the 16-bit compute dtype, x [m][512] float32 or NULL,
+ *     x_mid = x + fsmn + att Wo^T + b_o,   x_out = x_mid + W2 relu(W1 norm2(x_mid) + b1) + b2   (x_out may alias x)
+ * and, when y is not NULL, y [m][512] = x_out normalised to zero mean / unit variance per row, in the compute
+ * dtype (the next norm1's scale and shift are folded into the next layer's QKV weights).  flags != 0 are timing
+ * experiments that produce wrong results. */
+int32_t asrfe_debug_post_attn(asrfe_ctx* ctx, int32_t layer, const void* att, const void* fsmn, const float* x,
+                              float* x_out, void* y, int32_t m, int32_t flags, void* stream);
 
 /* Text of the last error on this context (or of the last failed asrfe_create when ctx is NULL). */
 const char* asrfe_last_error(const asrfe_ctx* ctx);

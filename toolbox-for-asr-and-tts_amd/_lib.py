@@ -58,7 +58,7 @@ class Config(C.Structure):
 
 
 PROF_KINDS = ["fbank", "frontend", "lfr_cmvn", "pe_table", "layernorm", "gemm_qkv", "fsmn", "attention", "gemm_out",
-              "gemm_ffn1", "gemm_ffn2", "ffn_fused"]
+              "gemm_ffn1", "gemm_ffn2", "post_attn"]
 
 
 class Profile(C.Structure):
@@ -99,8 +99,8 @@ SIGNATURES = {
     "asrfe_debug_gemm": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32,
                                      C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32,
                                      C.c_int32, C.c_void_p]),
-    "asrfe_debug_ffn": (C.c_int32, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32,
-                                    C.c_void_p]),
+    "asrfe_debug_post_attn": (C.c_int32, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                          C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
     "asrfe_last_error": (C.c_char_p, [C.c_void_p]),
     "asrfe_version": (C.c_char_p, []),
 }

@@ -378,21 +378,34 @@ static void fold_layernorm(const HostTensor* w, const HostTensor* c, const HostT
     }
 }
 
-// W1 [ff][512] and W2 [512][ff] as the piece stream of the fused feed-forward kernel: for every chunk j of 64
-// hidden units, four images of W1[64 j .. +64][128 ks .. +128] (64 rows of 256 bytes, 16-byte slot cs of row r
-// holding source chunk cs ^ (r & 15)) followed by four images of W2[128 nq .. +128][64 j .. +64] (128 rows of
-// 128 bytes, slot cs of row r holding source chunk cs ^ ((r >> 1) & 7)).  Inside every group of 16 columns the
-// k order is p -> swap of bits 2 and 3 of p, the order in which accumulator registers feed the next MFMA.
-static int32_t up_ffn_stream(asrfe_ctx* ctx, const HostTensor* w1, const HostTensor* w2, uint16_t** dev) {
+// Wo [512][512], W1 [ff][512] and W2 [512][ff] as the piece stream of the fused post-attention kernel (16 KiB
+// LDS images in consumption order).  Four chunks of Wo come first: piece r of chunk c is
+// Wo[128 (r & 3) .. +128][64 (2 c + (r >> 2)) .. +64] as 128 rows of 128 bytes, 16-byte slot cs of row r holding
+// source chunk cs ^ ((r >> 1) & 7).  Then, for every chunk j of 64 hidden units, four images of
+// W1[64 j .. +64][128 ks .. +128] (64 rows of 256 bytes, slot cs of row r holding source chunk cs ^ (r & 15))
+// followed by four images of W2[128 nq .. +128][64 j .. +64] (128-byte rows as for Wo).  Inside every group of 16
+// columns of W1 and W2 the k order is p -> swap of bits 2 and 3 of p, the order in which accumulator registers
+// feed the next MFMA; Wo keeps the natural order (its operand is loaded from memory).
+static int32_t up_layer_stream(asrfe_ctx* ctx, const HostTensor* wo, const HostTensor* w1, const HostTensor* w2,
+                               uint16_t** dev) {
     const int64_t ff = w1->shape[0], d = w1->shape[1];
     const bool f16 = ctx->cfg.enc_compute_dtype == ASRFE_DT_F16;
     auto cvt = [&](float w) { return f16 ? f16_rne(w) : bf16_rne(w); };
     auto swap23 = [](int64_t c) { return (c & ~int64_t{12}) | ((c & 4) << 1) | ((c & 8) >> 1); };
-    std::vector<uint16_t> v(static_cast<size_t>(2 * ff * d), 0);
     const int64_t nch = ff / 64;
+    std::vector<uint16_t> v(static_cast<size_t>((4 + nch) * 8 * 8192), 0);
+    for (int64_t c = 0; c < 4; ++c)
+        for (int64_t r8 = 0; r8 < 8; ++r8) {
+            uint16_t* img = v.data() + (8 * c + r8) * 8192;
+            const int64_t ks = 2 * c + (r8 >> 2), nq = r8 & 3;
+            for (int64_t r = 0; r < 128; ++r)
+                for (int64_t cs = 0; cs < 8; ++cs)
+                    for (int64_t e = 0; e < 8; ++e)
+                        img[(r * 8 + cs) * 8 + e] = cvt(wo->data[(128 * nq + r) * d + 64 * ks + 8 * (cs ^ ((r >> 1) & 7)) + e]);
+        }
     for (int64_t j = 0; j < nch; ++j) {
         for (int64_t ks = 0; ks < 4; ++ks) {
-            uint16_t* img = v.data() + (8 * j + ks) * 8192;
+            uint16_t* img = v.data() + (8 * (4 + j) + ks) * 8192;
             for (int64_t r = 0; r < 64; ++r)
                 for (int64_t cs = 0; cs < 16; ++cs)
                     for (int64_t e = 0; e < 8; ++e) {
@@ -401,7 +414,7 @@ static int32_t up_ffn_stream(asrfe_ctx* ctx, const HostTensor* w1, const HostTen
                     }
         }
         for (int64_t nq = 0; nq < 4; ++nq) {
-            uint16_t* img = v.data() + (8 * j + 4 + nq) * 8192;
+            uint16_t* img = v.data() + (8 * (4 + j) + 4 + nq) * 8192;
             for (int64_t r = 0; r < 128; ++r)
                 for (int64_t cs = 0; cs < 8; ++cs)
                     for (int64_t e = 0; e < 8; ++e) {
@@ -456,6 +469,7 @@ extern "C" int32_t asrfe_load_encoder_weights(asrfe_ctx* ctx, const asrfe_tensor
             if ((rc = upload(ctx, w, &L.w_fsmn))) return rc;
         }
         if ((rc = need(ctx, m, p + ".self_attn.linear_out.weight", {d, d}, &t)) || (rc = up_bf16(ctx, t, static_cast<int>(d), &L.w_out))) return rc;
+        const HostTensor* t_wo = t;
         if ((rc = need(ctx, m, p + ".self_attn.linear_out.bias", {d}, &t)) || (rc = up_f32(ctx, t, &L.b_out))) return rc;
         if ((rc = need(ctx, m, p + ".norm2.weight", {d}, &tg)) || (rc = need(ctx, m, p + ".norm2.bias", {d}, &tb)) ||
             (rc = need(ctx, m, p + ".feed_forward.w_1.weight", {ff, d}, &tw)) ||
@@ -465,8 +479,9 @@ extern "C" int32_t asrfe_load_encoder_weights(asrfe_ctx* ctx, const asrfe_tensor
         const HostTensor w1view{wfold.data(), tw->shape};
         if ((rc = up_bf16(ctx, &w1view, static_cast<int>(d), &L.w_ffn1)) || (rc = upload(ctx, cfold, &L.b_ffn1))) return rc;
         if ((rc = need(ctx, m, p + ".feed_forward.w_2.weight", {d, ff}, &t)) || (rc = up_bf16(ctx, t, static_cast<int>(ff), &L.w_ffn2))) return rc;
-        if (d != 512 || ff % 64 != 0) return set_err(ctx, ASRFE_ERR_SHAPE, "asrfe_load_encoder_weights: the fused feed-forward kernel needs d = 512 and linear_units % 64 == 0");
-        if ((rc = up_ffn_stream(ctx, &w1view, t, &L.w_ffn_stream))) return rc;
+        if (d != 512 || ff % 64 != 0 || ff > 7168)
+            return set_err(ctx, ASRFE_ERR_SHAPE, "asrfe_load_encoder_weights: the fused post-attention kernel needs d = 512 and linear_units a multiple of 64 up to 7168");
+        if ((rc = up_layer_stream(ctx, t_wo, &w1view, t, &L.w_stream))) return rc;
         if ((rc = need(ctx, m, p + ".feed_forward.w_2.bias", {d}, &t)) || (rc = up_f32(ctx, t, &L.b_ffn2))) return rc;
     }
     const HostTensor* t;
@@ -568,18 +583,19 @@ extern "C" int32_t asrfe_debug_gemm(asrfe_ctx* ctx, const void* a, int32_t lda, 
     return launch_gemm(ctx, g, epi, static_cast<hipStream_t>(stream));
 }
 
-extern "C" int32_t asrfe_debug_ffn(asrfe_ctx* ctx, int32_t layer, const float* x, float* x_out, void* y, int32_t m,
-                                   int32_t flags, void* stream) {
-    if (!ctx || !x || !x_out) return set_err(ctx, ASRFE_ERR_BAD_ARG, "asrfe_debug_ffn: null argument");
-    if (!ctx->enc_loaded) return set_err(ctx, ASRFE_ERR_NOT_LOADED, "asrfe_debug_ffn: encoder weights not loaded");
-    if (layer < 0 || layer >= ctx->cfg.enc_num_blocks) return set_err(ctx, ASRFE_ERR_BAD_ARG, "asrfe_debug_ffn: no such layer");
+extern "C" int32_t asrfe_debug_post_attn(asrfe_ctx* ctx, int32_t layer, const void* att, const void* fsmn, const float* x,
+                                         float* x_out, void* y, int32_t m, int32_t flags, void* stream) {
+    if (!ctx || !att || !fsmn || !x_out) return set_err(ctx, ASRFE_ERR_BAD_ARG, "asrfe_debug_post_attn: null argument");
+    if (!ctx->enc_loaded) return set_err(ctx, ASRFE_ERR_NOT_LOADED, "asrfe_debug_post_attn: encoder weights not loaded");
+    if (layer < 0 || layer >= ctx->cfg.enc_num_blocks) return set_err(ctx, ASRFE_ERR_BAD_ARG, "asrfe_debug_post_attn: no such layer");
     const LayerWeights& L = ctx->layers[layer];
     FfnParams f{};
+    f.att = static_cast<const uint16_t*>(att); f.fsmn = static_cast<const uint16_t*>(fsmn);
     f.x = x; f.x_out = x_out;
-    f.wstream = L.w_ffn_stream; f.b1 = L.b_ffn1; f.b2 = L.b_ffn2;
+    f.wstream = L.w_stream; f.bo = L.b_out; f.b1 = L.b_ffn1; f.b2 = L.b_ffn2;
     f.y = y; f.ldy = 512;
     f.eps = ctx->cfg.enc_ln_eps; f.M = m; f.ff = ctx->cfg.enc_linear_units; f.flags = flags;
-    return launch_ffn(ctx, f, static_cast<hipStream_t>(stream));
+    return launch_post_attn(ctx, f, static_cast<hipStream_t>(stream));
 }
 
 // ---- encoder entry points ----------------------------------------------------------------------

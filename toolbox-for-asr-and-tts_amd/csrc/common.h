@@ -61,9 +61,9 @@ struct LayerWeights {
     uint16_t* w_out; float* b_out;     // bf16 [512][512]
     uint16_t* w_ffn1; float* b_ffn1;   // bf16 [2048][512]
     uint16_t* w_ffn2; float* b_ffn2;   // bf16 [512][2048]
-    // both matrices again as the stream of 16 KiB LDS images the fused feed-forward kernel consumes, in the
-    // order it consumes them (layout: ffn.hip)
-    uint16_t* w_ffn_stream;
+    // w_out, w_ffn1 and w_ffn2 again as the stream of 16 KiB LDS images the fused post-attention kernel
+    // consumes, in the order it consumes them (layout: post_attn.hip)
+    uint16_t* w_stream;
 };
 
 }  // namespace asrfe

@@ -110,6 +110,20 @@ int32_t encoder_forward(asrfe_ctx* ctx, const float* feats, const int32_t* lens,
         { ProfScope ps(ctx, PK_ATTN, s); rc = launch_attention(ctx, a, s); }
         if (rc) return rc;
 
+        if (!ctx->unfused_ffn) {
+            // output projection + FSMN + residual, feed-forward, and h = the next layer's normalised input: one kernel
+            const bool has_next = li + 1 < c.enc_num_blocks;
+            FfnParams f{};
+            f.att = bf.att; f.fsmn = bf.fsmn;
+            f.x = li == 0 ? nullptr : bf.x; f.x_out = bf.x;
+            f.wstream = L.w_stream; f.bo = L.b_out; f.b1 = L.b_ffn1; f.b2 = L.b_ffn2;
+            f.y = has_next ? bf.h : nullptr; f.ldy = 512;
+            f.eps = c.enc_ln_eps; f.M = M; f.ff = ff;
+            { ProfScope ps(ctx, PK_FFN_FUSED, s); rc = launch_post_attn(ctx, f, s); }
+            if (rc) return rc;
+            continue;
+        }
+
         g = GemmParams{};
         g.A = bf.att; g.lda = 512; g.W = L.w_out; g.ldw = 512; g.bias = L.b_out;
         g.M = M; g.N = 512; g.K = 512; g.out = bf.x; g.ldo = 512;
@@ -117,19 +131,6 @@ int32_t encoder_forward(asrfe_ctx* ctx, const float* feats, const int32_t* lens,
         g.add32 = li == 0 ? nullptr : bf.x; g.ld32 = 512;
         { ProfScope ps(ctx, PK_GEMM_OUT, s); rc = launch_gemm(ctx, g, EPI_F32_ADD, s); }
         if (rc) return rc;
-
-        if (!ctx->unfused_ffn) {
-            // x = x + FFN(norm2(x)) and h = the next layer's normalised input, one kernel
-            const bool has_next = li + 1 < c.enc_num_blocks;
-            FfnParams f{};
-            f.x = bf.x; f.x_out = bf.x;
-            f.wstream = L.w_ffn_stream; f.b1 = L.b_ffn1; f.b2 = L.b_ffn2;
-            f.y = has_next ? bf.h : nullptr; f.ldy = 512;
-            f.eps = c.enc_ln_eps; f.M = M; f.ff = ff;
-            { ProfScope ps(ctx, PK_FFN_FUSED, s); rc = launch_ffn(ctx, f, s); }
-            if (rc) return rc;
-            continue;
-        }
 
         { ProfScope ps(ctx, PK_LN, s); rc = launch_ln512(ctx, bf.x, nullptr, nullptr, c.enc_ln_eps, M, bf.h, s); }
         if (rc) return rc;

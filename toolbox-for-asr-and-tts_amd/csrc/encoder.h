@@ -34,23 +34,26 @@ int32_t launch_ln512(asrfe_ctx* ctx, const float* x, const float* g, const float
 int32_t launch_ln_final(asrfe_ctx* ctx, const float* x, const float* g, const float* bta, float eps, int B, int Tp,
                         const int32_t* lens, void* out, int out_dtype, hipStream_t s);
 
-// Fused feed-forward block: x_out = x + W2 relu(W1 n(x) + b1) + b2, and optionally y = n(x_out) as 16-bit, where
-// n(.) normalises a row to zero mean and unit variance (the LayerNorm scale and shift live in the weights).
-// x_out may alias x.
+// Everything after the attention kernel in one launch (post_attn.hip):
+//     x_mid = x + fsmn + att Wo^T + b_o,   x_out = x_mid + W2 relu(W1 n(x_mid) + b1) + b2,   y = n(x_out) as 16-bit
+// where n(.) normalises a row to zero mean and unit variance (the LayerNorm scale and shift live in the weights).
+// x may be null (layer 0: no residual into the attention block); x_out may alias x.
 struct FfnParams {
-    const float* x;        // [M][512]
+    const uint16_t* att;   // [M][512] attention output, 16-bit
+    const uint16_t* fsmn;  // [M][512] FSMN memory, 16-bit
+    const float* x;        // [M][512] or null
     float* x_out;          // [M][512]
-    const uint16_t* wstream;  // W1 and W2 as the kernel's piece stream (LayerWeights::w_ffn_stream)
+    const uint16_t* wstream;  // Wo, W1 and W2 as the kernel's piece stream (LayerWeights::w_stream)
+    const float* bo;       // [512]
     const float* b1;       // [ff]
     const float* b2;       // [512]
     void* y;               // optional 16-bit [M][ldy] in the compute dtype
     int ldy;
     float eps;
     int M, ff;
-    int flags;             // timing experiments only (results are wrong): bit 0 skip the stores, bit 1 skip the weight
-                           // staging (builds with -DASRFE_FFN_TIMING=1 only)
+    int flags;             // timing experiments only (results are wrong): bit 0 skips the stores
 };
-int32_t launch_ffn(asrfe_ctx* ctx, const FfnParams& p, hipStream_t s);
+int32_t launch_post_attn(asrfe_ctx* ctx, const FfnParams& p, hipStream_t s);
 
 // FSMN memory block on V (columns 1024..1535 of qkv) and the transposed V copy for attention
 int32_t launch_fsmn(asrfe_ctx* ctx, const uint16_t* qkv, int ld_qkv, const float* w /*[11][512]*/, const int32_t* lens,

@@ -1,19 +1,22 @@
-// Fused position-wise feed-forward block of one SAN-M encoder layer on gfx950:
+// Everything of a SAN-M encoder layer that follows the attention kernel, in one kernel on gfx950:
 //
-//     x_out = x + W2 relu(W1 n(x) + b1) + b2             (fp32 residual stream, 512 columns)
+//     x_mid = x + fsmn + att Wo^T + b_o                   (attention output projection + FSMN memory + residual)
+//     x_out = x_mid + W2 relu(W1 n(x_mid) + b1) + b2      (position-wise feed-forward, fp32 residual stream)
 //     y     = n(x_out)  as 16-bit                          (optional: the next layer's normalised input)
-// n(.) normalises a row to zero mean and unit variance; the scale and shift of the two LayerNorms are folded
-// into W1 / b1 and into the next layer's QKV projection when the weights are loaded.
+// n(.) normalises a row of 512 to zero mean and unit variance; the scale and shift of the two LayerNorms are
+// folded into W1 / b1 and into the next layer's QKV projection when the weights are loaded.
 //
-// One workgroup = 128 rows of x, 4 waves, ONE wave per SIMD so that a wave may use the whole 512-entry
-// register file.  A wave owns 32 complete rows for the whole kernel:
-//   - the 32 x 512 fp32 output tile is 16 accumulators of v_mfma_f32_32x32x16 (256 registers) which start
-//     as x + b2, so the residual never leaves registers;
-//   - n(x) is computed inside the wave (a row lives in the two lanes l and l + 32) and kept as the 32
-//     MFMA operand fragments of the first GEMM (128 registers);
-//   - the hidden layer is produced 64 units at a time: H^T[64][32] = W1_chunk n(x)^T (2 accumulators),
+// One workgroup = 128 rows, 4 waves, ONE wave per SIMD so that a wave may use the whole 512-entry register
+// file.  A wave owns 32 complete rows for the whole kernel:
+//   - the 32 x 512 fp32 row tile is 16 accumulators of v_mfma_f32_32x32x16 (256 registers).  It starts as
+//     x + fsmn + b_o, the output projection accumulates into it, the row statistics are taken from it in
+//     registers (a row lives in the two lanes l and l + 32), b2 is added and the feed-forward accumulates
+//     into it again: neither x_mid nor the residual ever leaves registers;
+//   - att (32 x 512) and later n(x_mid) are kept as the 32 MFMA operand fragments of the GEMM they feed
+//     (128 registers, the same ones);
+//   - the hidden layer is produced 64 units at a time: H^T[64][32] = W1_chunk n(x_mid)^T (2 accumulators),
 //     ReLU + rounding turn it straight into the operand fragments of the second GEMM, which adds
-//     W2[:, chunk] H^T into the output tile.  The 2048-wide intermediate never exists in memory.
+//     W2[:, chunk] H^T into the row tile.  The 2048-wide intermediate never exists in memory.
 //
 // An accumulator holds 4 consecutive rows per register quad (row = 8 g + 4 (lane >> 5) + e), while an
 // operand fragment holds 8 consecutive k per lane (k = 8 (lane >> 5) + i).  Feeding accumulator registers
@@ -21,15 +24,17 @@
 // host stores the COLUMNS of W1 and W2 in that same order (asrfe_load_encoder_weights), which makes the
 // product exact again without moving any data on the device.
 //
-// Weights stream through LDS as 16 KiB pieces, 8 per chunk of 64 hidden units:
-//     pieces 0..3 : W1[chunk rows 64][128 k]    (256-byte rows, 16-byte slot c of row r holds chunk c ^ (r & 15))
-//     pieces 4..7 : W2[128 n][chunk cols 64]    (128-byte rows, slot c of row r holds chunk c ^ ((r >> 1) & 7))
-// The host stores both matrices as the stream of these images in consumption order
-// (asrfe_load_encoder_weights), so a piece is 16 KiB of contiguous memory copied by 16-byte LDS-DMA loads.
-// Piece r of every chunk uses ring slot r.  A wave issues 16 MFMAs per piece; the fragment for MFMA i + 8 is read right after
-// MFMA i, so in the middle of piece q the wave needs piece q + 1: there it waits (counted vmcnt: five
-// younger pieces stay in flight), meets the other waves at one s_barrier, and then refills the slot of
-// piece q - 1, whose last read every wave finished before that barrier.
+// Weights stream through LDS as 16 KiB pieces, 8 per chunk; a layer's stream is 4 chunks of Wo followed by one
+// chunk per 64 hidden units:
+//     Wo chunk c, piece r : Wo[128 (r & 3) .. +128][64 (2 c + (r >> 2)) .. +64]
+//     FFN pieces 0..3     : W1[chunk rows 64][128 k]   (256-byte rows, 16-byte slot c of row r holds chunk c ^ (r & 15))
+//     FFN pieces 4..7     : W2[128 n][chunk cols 64]
+// (128-byte rows: slot c of row r holds chunk c ^ ((r >> 1) & 7)).  The host stores the stream of these images
+// in consumption order, so a piece is 16 KiB of contiguous memory copied by 16-byte LDS-DMA loads.  Piece r
+// of every chunk uses ring slot r.  A wave issues 16 MFMAs per piece; the fragment for MFMA i + 8 is read right
+// after MFMA i, so in the middle of piece q the wave needs piece q + 1: there it waits (counted vmcnt: five
+// younger pieces stay in flight), meets the other waves at one s_barrier, and then refills the slot of piece
+// q - 1, whose last read every wave finished before that barrier.
 #include <utility>
 
 #include "common.h"
@@ -45,7 +50,7 @@ namespace asrfe {
 constexpr int kFfnThreads = 256;
 constexpr int kFfnRows = 128;
 constexpr int kPieceBytes = 16384;
-constexpr int kFfnRing = 8 * kPieceBytes;  // 128 KiB; the fp32 b1 and b2 vectors follow it
+constexpr int kFfnRing = 8 * kPieceBytes;  // 128 KiB; the fp32 b1, b2 and b_o vectors follow it
 
 // 16-byte LDS-DMA load: LDS[m0 + 16 * lane] = *(sbase + voff) (scalar base, 32-bit per-lane offset).  Issued through inline assembly on purpose: the compiler
 // models a load that touches both global memory and LDS as a flat access and, while one is pending, turns
@@ -150,8 +155,9 @@ __device__ __forceinline__ u16x8 pack8(float a0, float a1, float a2, float a3, f
     return __builtin_bit_cast(u16x8, v);
 }
 
+
 template <bool F16, bool HAS_Y>
-__global__ __launch_bounds__(kFfnThreads) void ffn_kernel(const FfnParams p) {
+__global__ __launch_bounds__(kFfnThreads) void post_attn_kernel(const FfnParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -160,87 +166,184 @@ __global__ __launch_bounds__(kFfnThreads) void ffn_kernel(const FfnParams p) {
     const int row0 = blockIdx.x * kFfnRows + wave * 32;
     const int nch = p.ff >> 6;
     float* b1s = reinterpret_cast<float*>(smem + kFfnRing);
+    float* b2s = b1s + p.ff;   // the bias vectors live in LDS: a global load per use would be waited for one by one
+    float* bos = b2s + 512;
 
-    // ---- staging: the weights arrive as a stream of ready-made 16 KiB LDS images (piece 8 j + r of chunk j), so a
-    //      wave copies four contiguous 1 KiB runs per piece
+    // ---- staging: the weights arrive as a stream of ready-made 16 KiB LDS images, so a wave copies four
+    //      contiguous 1 KiB runs per piece
     const char* wsrc = reinterpret_cast<const char*>(p.wstream);
     const uint32_t wlane = wave * 1024 + lane * 16;
     const uint32_t smem_base = __builtin_amdgcn_readfirstlane(lds_addr_of(smem));
-    // timing experiments only (bit 1 needs a build with -DASRFE_FFN_TIMING=1: the test costs issue slots)
-    const bool no_store = p.flags & 1;
-    [[maybe_unused]] const bool no_stage = p.flags & 2;
+    const bool no_store = p.flags & 1;  // timing experiments only
     // quarter i (4 KiB: one 1 KiB run per wave) of piece R of the chunk whose eight pieces start at cbase
     auto stage_quarter = [&](auto rc, const char* cbase, int i) {
         constexpr int R = decltype(rc)::value;
-#if ASRFE_FFN_TIMING
-        if (no_stage) return;
-#endif
         const uint32_t dst = __builtin_amdgcn_readfirstlane(smem_base + R * kPieceBytes + wave * 1024);
         ffn_glds16(cbase + R * kPieceBytes + i * 4096, wlane, dst + i * 4096);
     };
-    auto chunk_base = [&](int j) { return wsrc + static_cast<int64_t>(j) * (8 * kPieceBytes); };
+    // chunk c of the layer's stream: 0..3 are Wo, 4 + j is hidden chunk j
+    auto chunk_base = [&](int c) { return wsrc + static_cast<int64_t>(c) * (8 * kPieceBytes); };
     auto stage = [&](auto rc, const char* cbase) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) stage_quarter(rc, cbase, i);
     };
-    // the first four pieces fly while x is loaded and normalised; slots 4..7 serve as x staging until then
+    // the first four pieces fly while the activations are loaded; slots 4..7 serve as their staging until then
     const char* cb_first = chunk_base(0);
     stage(IC<0>{}, cb_first); stage(IC<1>{}, cb_first); stage(IC<2>{}, cb_first); stage(IC<3>{}, cb_first);
 
     for (int i = tid * 4; i < p.ff; i += kFfnThreads * 4)
         *reinterpret_cast<float4*>(b1s + i) = *reinterpret_cast<const float4*>(p.b1 + i);
-    float* b2s = b1s + p.ff;  // both bias vectors live in LDS: a global load per use would be waited for one by one
     if (tid < 128) *reinterpret_cast<float4*>(b2s + tid * 4) = *reinterpret_cast<const float4*>(p.b2 + tid * 4);
+    else *reinterpret_cast<float4*>(bos + (tid - 128) * 4) = *reinterpret_cast<const float4*>(p.bo + (tid - 128) * 4);
+    __syncthreads();
 
-    // ---- x in accumulator layout: register 4 g + e of tile nt is column 32 nt + 8 g + 4 h + e of row l31.
-    //      x also comes in by LDS-DMA (no staging registers): a 32-row x 32-column tile is a 4 KiB slab of 128-byte
-    //      rows, 16-byte slot c of row r holding chunk c ^ (r & 7), filled by four loads whose per-lane source
-    //      addresses carry the swizzle.  Every wave owns ring slot 4 + wave as four such slabs, refilled as they are
-    //      consumed, so three tiles are always in flight.  Two passes over the tile registers follow, one tile in
-    //      working registers at a time (tile_in / tile_out pin the moves).
+    // ---- activations.  att, fsmn and x come in by LDS-DMA (no staging registers) as 4 KiB slabs of 32 rows x
+    //      128 bytes, filled by four loads whose per-lane source addresses carry the bank swizzle.  Every wave owns
+    //      ring slot 4 + wave as four such slabs, refilled as they are consumed, so three slabs are always in
+    //      flight.  Slab order: att k-slices 0..7, then per 64 columns: fsmn, x tile 2 p, x tile 2 p + 1.
+    //      Row tile layout: register 4 g + e of tile nt is column 32 nt + 8 g + 4 h + e of row l31.
     f32x16 oacc[16];
-    u16x8 afrag[32];  // n(x) as operand fragments: afrag[2 nt + q] = registers 8 q .. 8 q + 7 of tile nt
+    u16x8 afrag[32];  // att, later n(x_mid), as operand fragments: fragment s covers k = 16 s .. 16 s + 15
     {
         const uint32_t xs_lds = __builtin_amdgcn_readfirstlane(smem_base + (4 + wave) * kPieceBytes);
         const char* xs = smem + (4 + wave) * kPieceBytes;
         // the per-lane offset is an UNSIGNED 32-bit addend of the scalar base, so the base is the wave's first valid
         // row and rows past M - 1 re-read row M - 1 (never a negative offset)
         const int rbase = min(row0, p.M - 1);
-        const char* xsrc = reinterpret_cast<const char*>(p.x) + static_cast<int64_t>(rbase) * 2048;
-        uint32_t xoff[4];  // lane's source offset for rows 8 k + (lane >> 3)
+        const bool has_x = p.x != nullptr;  // layer 0 has no residual into the attention block: x counts as zero
+        const char* xsrc = reinterpret_cast<const char*>(has_x ? p.x : p.x_out) + static_cast<int64_t>(rbase) * 2048;
+        const char* asrc = reinterpret_cast<const char*>(p.att) + static_cast<int64_t>(rbase) * 1024;
+        const char* fsrc = reinterpret_cast<const char*>(p.fsmn) + static_cast<int64_t>(rbase) * 1024;
+        uint32_t xoff[4], aoff[4];  // lane's source offsets for rows 8 k + (lane >> 3): 2 KiB rows (x) and 1 KiB rows
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const int r = 8 * k + (lane >> 3);
             const int rr = min(row0 + r, p.M - 1) - rbase;
             xoff[k] = static_cast<uint32_t>(rr * 2048 + (((lane & 7) ^ (r & 7)) << 4));
+            aoff[k] = static_cast<uint32_t>(rr * 1024 + (((lane & 7) ^ (r & 7)) << 4));
         }
-        auto x_tile_dma = [&](int nt) {
+        // slab i of the sequence -> its four loads into slab slot i & 3
+        auto slab_dma = [&](auto ic) {
+            constexpr int I = decltype(ic)::value;
+            const uint32_t dst = xs_lds + (I & 3) * 4096;
+            if constexpr (I < 8) {
 #pragma unroll
-            for (int k = 0; k < 4; ++k) ffn_glds16(xsrc + nt * 128, xoff[k], xs_lds + (nt & 3) * 4096 + k * 1024);
+                for (int k = 0; k < 4; ++k) ffn_glds16(asrc + I * 128, aoff[k], dst + k * 1024);
+            } else if constexpr ((I - 8) % 3 == 0) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) ffn_glds16(fsrc + ((I - 8) / 3) * 128, aoff[k], dst + k * 1024);
+            } else {
+                constexpr int nt = 2 * ((I - 8) / 3) + ((I - 8) % 3 - 1);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) ffn_glds16(xsrc + nt * 128, xoff[k], dst + k * 1024);
+            }
         };
-        x_tile_dma(0); x_tile_dma(1); x_tile_dma(2); x_tile_dma(3);
+        slab_dma(IC<0>{}); slab_dma(IC<1>{}); slab_dma(IC<2>{}); slab_dma(IC<3>{});
+        uint2 fs[8];  // the current fsmn slab in row-tile layout: fs[4 ns + g] = 4 values of tile 2 p + ns
+        static_for<32>([&](auto ic) {
+            constexpr int I = decltype(ic)::value;
+            // slab I has landed once at most the loads of the slabs behind it are outstanding (in-order counter)
+            if constexpr (I <= 28) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+            else if constexpr (I == 29) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else if constexpr (I == 30) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const char* sl = xs + (I & 3) * 4096 + l31 * 128;
+            const int sw = l31 & 7;
+            if constexpr (I < 8) {
+#pragma unroll
+                for (int s = 0; s < 4; ++s)
+                    afrag[4 * I + s] = *reinterpret_cast<const u16x8*>(sl + (((2 * s + h) ^ sw) << 4));
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(afrag[4 * I]), "+v"(afrag[4 * I + 1]), "+v"(afrag[4 * I + 2]), "+v"(afrag[4 * I + 3]) : : "memory");
+            } else if constexpr ((I - 8) % 3 == 0) {
+#pragma unroll
+                for (int q = 0; q < 8; ++q) fs[q] = *reinterpret_cast<const uint2*>(sl + ((q ^ sw) << 4) + 8 * h);
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fs[0]), "+v"(fs[1]), "+v"(fs[2]), "+v"(fs[3]), "+v"(fs[4]), "+v"(fs[5]), "+v"(fs[6]), "+v"(fs[7]) : : "memory");
+            } else {
+                constexpr int ns = (I - 8) % 3 - 1, nt = 2 * ((I - 8) / 3) + ns;
+                f32x16 t;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const float4 v = *reinterpret_cast<const float4*>(sl + (((2 * g + h) ^ sw) << 4));
+                    t[4 * g] = v.x; t[4 * g + 1] = v.y; t[4 * g + 2] = v.z; t[4 * g + 3] = v.w;
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(t) : : "memory");  // the slab is read before it is refilled
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    float f0, f1, f2, f3;
+                    unpack_elem2<F16>(fs[4 * ns + g].x, f0, f1);
+                    unpack_elem2<F16>(fs[4 * ns + g].y, f2, f3);
+                    const float4 bo4 = *reinterpret_cast<const float4*>(bos + 32 * nt + 8 * g + 4 * h);
+                    if (has_x) {
+                        t[4 * g] += f0 + bo4.x; t[4 * g + 1] += f1 + bo4.y; t[4 * g + 2] += f2 + bo4.z; t[4 * g + 3] += f3 + bo4.w;
+                    } else {
+                        t[4 * g] = f0 + bo4.x; t[4 * g + 1] = f1 + bo4.y; t[4 * g + 2] = f2 + bo4.z; t[4 * g + 3] = f3 + bo4.w;
+                    }
+                }
+                tile_in(oacc[nt], t);
+            }
+            if constexpr (I + 4 < 32) slab_dma(IC<I + 4>{});
+        });
+        // every wave is done with its slabs: slots 4..6 can take their weight pieces
+        __syncthreads();
+        stage(IC<4>{}, cb_first); stage(IC<5>{}, cb_first); stage(IC<6>{}, cb_first);
+    }
+
+    // ---- fragment reads: kind 1 = W1 piece (256-byte rows), kind 2 = Wo / W2 piece (128-byte rows)
+    int rb1 = l31 * 256, sw1 = (h ^ (l31 & 15)) << 4;
+    int rb2 = l31 * 128, sw2 = (h ^ ((l31 >> 1) & 7)) << 4;
+    auto frag1 = [&](auto rc, auto fc) -> u16x8 {  // W1 rows 32 ct + l31, k-step s of the piece
+        constexpr int R = decltype(rc)::value, F = decltype(fc)::value;
+        constexpr int s = F >> 1, ct = F & 1;
+        return *reinterpret_cast<const u16x8*>(smem + R * kPieceBytes + ct * 8192 + rb1 + (sw1 ^ (s << 5)));
+    };
+    auto frag2 = [&](auto rc, auto fc) -> u16x8 {  // rows 32 ntl + l31, k-step kk of the piece
+        constexpr int R = decltype(rc)::value, F = decltype(fc)::value;
+        constexpr int kk = F >> 2, ntl = F & 3;
+        return *reinterpret_cast<const u16x8*>(smem + R * kPieceBytes + ntl * 4096 + rb2 + (sw2 ^ (kk << 5)));
+    };
+    u16x8 wf[8];     // rolling weight fragments
+
+    wait_vm_barrier<24>();  // piece 0 has landed everywhere
+    static_for<8>([&](auto f) { wf[decltype(f)::value] = frag2(IC<0>{}, f); });
+
+    // ---- output projection: the row tile += att Wo^T, 4 chunks of 8 pieces
+    static_for<4>([&](auto cc) {
+        constexpr int C = decltype(cc)::value;
+        const char* cb0 = chunk_base(C);
+        const char* cb1 = chunk_base(C + 1);
+        static_for<8>([&](auto rc) {
+            constexpr int R = decltype(rc)::value;
+            constexpr int ks = 2 * C + (R >> 2), nq = R & 3;
+            static_for<8>([&](auto f) {
+                constexpr int F = decltype(f)::value;
+                mfma_agpr<F16>(oacc[4 * nq + (F & 3)], wf[F], afrag[4 * ks + (F >> 2)]);
+                wf[F] = frag2(rc, IC<F + 8>{});
+            });
+            wait_vm_barrier<20>();
+            static_for<8>([&](auto f) {
+                constexpr int F = decltype(f)::value;
+                mfma_agpr<F16>(oacc[4 * nq + (F & 3)], wf[F], afrag[4 * ks + 2 + (F >> 2)]);
+                if constexpr (C == 3 && R == 7) wf[F] = frag1(IC<0>{}, f);
+                else wf[F] = frag2(IC<((R + 1) & 7)>{}, f);
+                if constexpr ((F & 1) == 0) {
+                    if constexpr (R == 0) stage_quarter(IC<7>{}, cb0, F >> 1);
+                    else stage_quarter(IC<(R + 7) & 7>{}, cb1, F >> 1);
+                }
+            });
+        });
+    });
+
+    // ---- x_mid is complete: row statistics, n(x_mid) as the operand fragments of W1, and b2 into the row tile.
+    //      The compiler does not see inside the asm MFMAs, so the wait states between the last of them and the
+    //      first read of their results are covered by hand (volatile asm statements keep their order).
+    asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");
+    {
         float mean = 0.0f, m2 = 0.0f, rstd;
 #pragma unroll
         for (int nt = 0; nt < 16; ++nt) {
-            // tile nt has landed once at most the loads of the tiles behind it are outstanding (in-order counter)
-            if (nt <= 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-            else if (nt == 13) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-            else if (nt == 14) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            f32x16 t;
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const float4 v = *reinterpret_cast<const float4*>(xs + (nt & 3) * 4096 + l31 * 128 + (((2 * g + h) ^ (l31 & 7)) << 4));
-                t[4 * g] = v.x; t[4 * g + 1] = v.y; t[4 * g + 2] = v.z; t[4 * g + 3] = v.w;
-            }
-            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(t) : : "memory");  // the slab is read before it is refilled
-            if (nt + 4 < 16) x_tile_dma(nt + 4);
+            const f32x16 t = tile_out(oacc[nt]);
             stat_merge_tile(mean, m2, 16 * nt, t);
-            tile_in(oacc[nt], t);
         }
-        // every wave is done with its x slabs: slots 4..6 can take their weight pieces
-        __syncthreads();
-        stage(IC<4>{}, cb_first); stage(IC<5>{}, cb_first); stage(IC<6>{}, cb_first);
         stat_finish_row(mean, m2, p.eps, rstd);
         const float shift = -mean * rstd;
 #pragma unroll
@@ -250,15 +353,9 @@ __global__ __launch_bounds__(kFfnThreads) void ffn_kernel(const FfnParams p) {
             for (int q = 0; q < 2; ++q) {
                 float v[8];
 #pragma unroll
-                for (int gg = 0; gg < 2; ++gg) {
-                    v[4 * gg + 0] = t[8 * q + 4 * gg + 0] * rstd + shift;
-                    v[4 * gg + 1] = t[8 * q + 4 * gg + 1] * rstd + shift;
-                    v[4 * gg + 2] = t[8 * q + 4 * gg + 2] * rstd + shift;
-                    v[4 * gg + 3] = t[8 * q + 4 * gg + 3] * rstd + shift;
-                }
+                for (int e = 0; e < 8; ++e) v[e] = t[8 * q + e] * rstd + shift;
                 afrag[2 * nt + q] = pack8<F16>(v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7]);
             }
-            // the output tile starts as x + b2
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const float4 u = *reinterpret_cast<const float4*>(b2s + 32 * nt + 8 * g + 4 * h);
@@ -268,23 +365,9 @@ __global__ __launch_bounds__(kFfnThreads) void ffn_kernel(const FfnParams p) {
         }
     }
 
-    // ---- fragment reads
-    const int rb1 = l31 * 256, sw1 = (h ^ (l31 & 15)) << 4;
-    const int rb2 = l31 * 128, sw2 = (h ^ ((l31 >> 1) & 7)) << 4;
-    auto frag = [&](auto rc, auto fc) -> u16x8 {
-        constexpr int R = decltype(rc)::value, F = decltype(fc)::value;
-        if constexpr (R < 4) {  // W1 rows 32 ct + l31, k-step s of the piece
-            constexpr int s = F >> 1, ct = F & 1;
-            return *reinterpret_cast<const u16x8*>(smem + R * kPieceBytes + ct * 8192 + rb1 + (sw1 ^ (s << 5)));
-        } else {                // W2 rows 32 ntl + l31, k-step kk of the chunk
-            constexpr int kk = F >> 2, ntl = F & 3;
-            return *reinterpret_cast<const u16x8*>(smem + R * kPieceBytes + ntl * 4096 + rb2 + (sw2 ^ (kk << 5)));
-        }
-    };
-
+    // ---- feed-forward
     f32x16 acc1[2];  // H^T of the current chunk: register 4 g + e of tile ct is hidden unit 32 ct + 8 g + 4 h + e
     u16x8 hp[4];     // relu(H) as operand fragments of the second GEMM
-    u16x8 wf[8];     // rolling weight fragments
     auto init_acc1 = [&](int j) {
 #pragma unroll
         for (int ct = 0; ct < 2; ++ct)
@@ -304,7 +387,11 @@ __global__ __launch_bounds__(kFfnThreads) void ffn_kernel(const FfnParams p) {
             mfma_agpr<F16>(oacc[4 * (R - 4) + ntl], wf[F & 7], hp[kk]);
         }
     };
-    // piece R of chunk j; LAST: j is the final chunk (nothing further to stage)
+    auto frag = [&](auto rc, auto fc) -> u16x8 {
+        if constexpr (decltype(rc)::value < 4) return frag1(rc, fc);
+        else return frag2(rc, fc);
+    };
+    // piece R of hidden chunk j; LAST: j is the final chunk (nothing further to stage)
     auto step = [&](auto rc, int j, const char* cb0, const char* cb1, auto lastc) {
         constexpr int R = decltype(rc)::value;
         constexpr bool LAST = decltype(lastc)::value;
@@ -313,13 +400,13 @@ __global__ __launch_bounds__(kFfnThreads) void ffn_kernel(const FfnParams p) {
             mma(rc, f);
             wf[F] = frag(rc, IC<F + 8>{});
         });
-        // An LDS-DMA instruction holds the wave's issue for tens of cycles, so the four of a piece are spread
-        // over the MFMA gaps of the second half instead of being issued back to back.
         if constexpr (!LAST) wait_vm_barrier<20>();
         else wait_vm_barrier<(R <= 1 ? 20 : (R <= 6 ? 4 * (6 - R) : 0))>();
         // the hidden-chunk accumulators are idle from the ReLU to the end of the chunk: reload them with the next
         // chunk's bias here, eight MFMAs ahead of their first use
         if constexpr (R == 7 && !LAST) init_acc1(j + 1);
+        // An LDS-DMA instruction holds the wave's issue for tens of cycles, so the four of a piece are spread
+        // over the MFMA gaps of the second half instead of being issued back to back.
         static_for<8>([&](auto f) {
             constexpr int F = decltype(f)::value;
             mma(rc, IC<F + 8>{});
@@ -331,15 +418,19 @@ __global__ __launch_bounds__(kFfnThreads) void ffn_kernel(const FfnParams p) {
         });
     };
     auto chunk = [&](int j, auto lastc) {
+        // The fragment addresses are cheap to form from these four values (one add or xor each).  Making the values
+        // opaque once per chunk keeps the compiler from hoisting all the addresses out of the loop, where they
+        // do not fit in registers and come back as scratch reloads - whose vmcnt(0) waits would drain the DMA queue.
+        asm volatile("" : "+v"(rb1), "+v"(sw1), "+v"(rb2), "+v"(sw2));
         // this chunk's and the next chunk's pieces in the weight stream (uniform: scalar registers)
-        const char* cb0 = chunk_base(j);
-        const char* cb1 = chunk_base(j + 1);
+        const char* cb0 = chunk_base(4 + j);
+        const char* cb1 = chunk_base(5 + j);
         step(IC<0>{}, j, cb0, cb1, lastc);
         step(IC<1>{}, j, cb0, cb1, lastc);
         step(IC<2>{}, j, cb0, cb1, lastc);
         step(IC<3>{}, j, cb0, cb1, lastc);
-        // The compiler does not see inside the asm MFMAs, so the wait states between an MFMA and a VALU read of
-        // its result are covered by hand; the nops are tied to both tiles so that no read can move above them.
+        // MFMA-result-to-VALU wait states by hand again; the nops are tied to both tiles so that no read can move
+        // above them
         asm volatile("s_nop 15\n\ts_nop 7" : "+v"(acc1[0]), "+v"(acc1[1]));
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
@@ -354,15 +445,10 @@ __global__ __launch_bounds__(kFfnThreads) void ffn_kernel(const FfnParams p) {
         step(IC<7>{}, j, cb0, cb1, lastc);
     };
 
-    __syncthreads();  // b1 is in LDS
     init_acc1(0);
-    wait_vm_barrier<24>();  // piece 0 has landed everywhere
-    static_for<8>([&](auto f) { wf[decltype(f)::value] = frag(IC<0>{}, f); });
-
     for (int j = 0; j < nch - 1; ++j) chunk(j, std::false_type{});
     chunk(nch - 1, std::true_type{});
     __syncthreads();  // every wave is done with the ring: it becomes the epilogue's staging area
-
     // ---- epilogue: 32-row slabs through a wave-private 4 KiB LDS tile so that global stores move whole
     //      128-byte lines (8 consecutive lanes per row)
     char* es = smem + wave * 8192;  // fp32 slab of x_out
@@ -429,36 +515,36 @@ __global__ __launch_bounds__(kFfnThreads) void ffn_kernel(const FfnParams p) {
     }
 }
 
-int32_t launch_ffn(asrfe_ctx* ctx, const FfnParams& p, hipStream_t s) {
+int32_t launch_post_attn(asrfe_ctx* ctx, const FfnParams& p, hipStream_t s) {
     if (p.M <= 0) return ASRFE_OK;
-    if (p.ff < 64 || p.ff % 64 != 0 || p.ff > 7680)
-        return set_err(ctx, ASRFE_ERR_SHAPE, "ffn: linear_units must be a multiple of 64 in 64..7680");
-    if (!p.x || !p.x_out || !p.wstream || !p.b1 || !p.b2 || (p.y && p.ldy % 8 != 0))
-        return set_err(ctx, ASRFE_ERR_BAD_ARG, "ffn: null or misaligned argument");
-    const int lds = kFfnRing + p.ff * 4 + 512 * 4;
+    if (p.ff < 64 || p.ff % 64 != 0 || p.ff > 7168)
+        return set_err(ctx, ASRFE_ERR_SHAPE, "post_attn: linear_units must be a multiple of 64 in 64..7168");
+    if (!p.att || !p.fsmn || !p.x_out || !p.wstream || !p.bo || !p.b1 || !p.b2 || (p.y && p.ldy % 8 != 0))
+        return set_err(ctx, ASRFE_ERR_BAD_ARG, "post_attn: null or misaligned argument");
+    const int lds = kFfnRing + p.ff * 4 + 2 * 512 * 4;
     const dim3 grid((p.M + kFfnRows - 1) / kFfnRows), block(kFfnThreads);
     const bool f16 = ctx->cfg.enc_compute_dtype == ASRFE_DT_F16;
-#define FFN_LAUNCH(F, Y)                                                                                        \
+#define POST_ATTN_LAUNCH(F, Y)                                                                                  \
     do {                                                                                                        \
         static bool attr_done = false;                                                                          \
         if (!attr_done) {                                                                                       \
-            if (hipFuncSetAttribute(reinterpret_cast<const void*>(ffn_kernel<F, Y>),                         \
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(post_attn_kernel<F, Y>),                      \
                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)      \
-                return set_err(ctx, ASRFE_ERR_HIP, "ffn: cannot raise the dynamic LDS limit to 160 KiB");       \
+                return set_err(ctx, ASRFE_ERR_HIP, "post_attn: cannot raise the dynamic LDS limit to 160 KiB"); \
             attr_done = true;                                                                                   \
         }                                                                                                       \
-        hipLaunchKernelGGL((ffn_kernel<F, Y>), grid, block, lds, s, p);                                      \
+        hipLaunchKernelGGL((post_attn_kernel<F, Y>), grid, block, lds, s, p);                                   \
     } while (0)
     if (f16) {
-        if (p.y) FFN_LAUNCH(true, true);
-        else FFN_LAUNCH(true, false);
+        if (p.y) POST_ATTN_LAUNCH(true, true);
+        else POST_ATTN_LAUNCH(true, false);
     } else {
-        if (p.y) FFN_LAUNCH(false, true);
-        else FFN_LAUNCH(false, false);
+        if (p.y) POST_ATTN_LAUNCH(false, true);
+        else POST_ATTN_LAUNCH(false, false);
     }
-#undef FFN_LAUNCH
+#undef POST_ATTN_LAUNCH
     const hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return set_err(ctx, ASRFE_ERR_HIP, std::string("ffn launch: ") + hipGetErrorString(e));
+    if (e != hipSuccess) return set_err(ctx, ASRFE_ERR_HIP, std::string("post_attn launch: ") + hipGetErrorString(e));
     return ASRFE_OK;
 }
 

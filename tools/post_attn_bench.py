@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Times and checks the fused feed-forward kernel in isolation (through asrfe_debug_ffn).
+"""Times and checks the fused post-attention kernel in isolation (through asrfe_debug_post_attn).
 
     python tools/ffn_bench.py [--check] [--iters 30] [--flags 0 1 2 ...]
 """
@@ -34,30 +34,47 @@ def main():
     ctx, lib = enc.ctx, enc.ctx.lib
     dev = "cuda"
     stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    def tens(m):
+        att = (torch.randn(m, 512, device=dev) * 0.5).half()
+        fsmn = (torch.randn(m, 512, device=dev) * 0.5).half()
+        return att, fsmn
+
     if args.check:
+        g = {k: v.to(dev).float() for k, v in sd.items()}
+        pfx = "encoders0.0."
         for m in (1, 33, 128, 1000):
-            x = torch.randn(m, 512, device=dev) * 2.0 + 0.3
-            xo = torch.empty_like(x)
-            y = torch.empty(m, 512, device=dev, dtype=torch.float16)
-            ctx.check(lib.asrfe_debug_ffn(ctx.handle, 0, x.data_ptr(), xo.data_ptr(), y.data_ptr(), m, 0, stream))
-            g = {k: v.to(dev).float() for k, v in sd.items()}
-            pfx = "encoders0.0."
-            h = torch.nn.functional.layer_norm(x, (512,), g[pfx + "norm2.weight"], g[pfx + "norm2.bias"], 1e-12)
-            h = torch.relu(h.half().float() @ g[pfx + "feed_forward.w_1.weight"].half().float().T + g[pfx + "feed_forward.w_1.bias"])
-            ref = x + h.half().float() @ g[pfx + "feed_forward.w_2.weight"].half().float().T + g[pfx + "feed_forward.w_2.bias"]
-            yref = torch.nn.functional.layer_norm(ref, (512,), None, None, 1e-12)  # scale / shift live in the next QKV
-            e1 = (xo - ref).abs().max().item()
-            e2 = (y.float() - yref).abs().max().item()
-            print(f"check m={m}: x_out err {e1:.3e}, y err {e2:.3e}")
-            assert e1 < 2e-3 and e2 < 1e-2
+            for with_x in (True, False):
+                x = torch.randn(m, 512, device=dev) * 2.0 + 0.3
+                att, fsmn = tens(m)
+                xo = torch.empty_like(x)
+                y = torch.empty(m, 512, device=dev, dtype=torch.float16)
+                ctx.check(lib.asrfe_debug_post_attn(ctx.handle, 0, att.data_ptr(), fsmn.data_ptr(),
+                                                    x.data_ptr() if with_x else None, xo.data_ptr(), y.data_ptr(), m, 0, stream))
+                xm = att.float() @ g[pfx + "self_attn.linear_out.weight"].half().float().T + g[pfx + "self_attn.linear_out.bias"] + fsmn.float()
+                if with_x:
+                    xm = xm + x
+                h = torch.nn.functional.layer_norm(xm, (512,), g[pfx + "norm2.weight"], g[pfx + "norm2.bias"], 1e-12)
+                h = torch.relu(h.half().float() @ g[pfx + "feed_forward.w_1.weight"].half().float().T + g[pfx + "feed_forward.w_1.bias"])
+                ref = xm + h.half().float() @ g[pfx + "feed_forward.w_2.weight"].half().float().T + g[pfx + "feed_forward.w_2.bias"]
+                yref = torch.nn.functional.layer_norm(ref, (512,), None, None, 1e-12)  # scale / shift live in the next QKV
+                e1 = (xo - ref).abs().max().item()
+                e2 = (y.float() - yref).abs().max().item()
+                print(f"check m={m} x={'yes' if with_x else 'no '}: x_out err {e1:.3e}, y err {e2:.3e}")
+                assert e1 < 3e-3 and e2 < 1e-2
     m = args.rows
     x = torch.randn(m, 512, device=dev)
     y = torch.empty(m, 512, device=dev, dtype=torch.float16)
+    att, fsmn = tens(m)
+
+    def launch(flags):
+        ctx.check(lib.asrfe_debug_post_attn(ctx.handle, 0, att.data_ptr(), fsmn.data_ptr(), x.data_ptr(), x.data_ptr(),
+                                            y.data_ptr(), m, flags, stream))
+
     import time
     t0 = time.time()
     while time.time() - t0 < 1.5:  # let the clocks settle before the first measurement
         for _ in range(50):
-            ctx.check(lib.asrfe_debug_ffn(ctx.handle, 0, x.data_ptr(), x.data_ptr(), y.data_ptr(), m, 0, stream))
+            launch(0)
         x.normal_()
         torch.cuda.synchronize()
     # clock reference: boxes differ by up to ~10 %, so every run also times the plain GEMM (FFN1 shape)
@@ -82,7 +99,7 @@ def main():
     ref_gemm()
     for flags in args.flags * args.repeat:
         def run():
-            ctx.check(lib.asrfe_debug_ffn(ctx.handle, 0, x.data_ptr(), x.data_ptr(), y.data_ptr(), m, flags, stream))
+            launch(flags)
         x.normal_()
         for _ in range(3):
             run()
@@ -93,7 +110,7 @@ def main():
         e1.record()
         torch.cuda.synchronize()
         us = 1e3 * e0.elapsed_time(e1) / args.iters
-        print(f"ffn M={m} flags={flags}: {us:7.1f} us  {2.0 * m * 2048 * 512 * 2 / us / 1e6:7.1f} TFLOP/s")
+        print(f"post_attn M={m} flags={flags}: {us:7.1f} us  {2.0 * m * (2048 * 512 * 2 + 512 * 512) / us / 1e6:7.1f} TFLOP/s")
     ref_gemm()
 
 
