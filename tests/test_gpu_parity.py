@@ -302,3 +302,86 @@ def test_engine_end_to_end_matches_oracle(pkg):
     assert olens.cpu().tolist() == wl.tolist()
     want, _ = so.encoder_forward(torch.from_numpy(wf).float(), torch.from_numpy(wl), sd, cfg_o)
     assert float((out.cpu() - want).abs().max()) <= ENC_TOL
+
+
+def _trained_like(sd, seed):
+    """LayerNorm scale / shift and all biases away from their init values, as in a trained checkpoint: the
+    library folds norm1 / norm2 into the linear layers behind them, which the gamma = 1, beta = 0 goldens cannot see."""
+    g = torch.Generator().manual_seed(seed)
+    out = {}
+    for k, v in sd.items():
+        if "norm" in k and k.endswith(".weight"):
+            out[k] = v * (1.0 + 0.3 * torch.randn(v.shape, generator=g, dtype=v.dtype))
+        elif "norm" in k and k.endswith(".bias"):
+            out[k] = v + 0.2 * torch.randn(v.shape, generator=g, dtype=v.dtype)
+        else:
+            out[k] = v
+    return out
+
+
+def test_encoder_nontrivial_layernorm_parameters(pkg):
+    """3 layers with random LayerNorm gamma / beta (including after_norm) against the oracle."""
+    cfg = so.SanmConfig(num_blocks=3)
+    sd = _trained_like(so.make_state_dict(cfg, seed=9, dtype=torch.float32), seed=10)
+    lens = torch.tensor([150, 97, 128], dtype=torch.int32)
+    feats = so.synth_feats(3, 150, 560, seed=33)
+    enc = pkg.SANMEncoder(num_blocks=3)
+    enc.load_state_dict(sd)
+    out, olens, _ = enc.forward(feats.cuda(), lens)
+    want, wl = so.encoder_forward(feats.double(), lens, {k: v.double() for k, v in sd.items()}, cfg)
+    assert olens.cpu().tolist() == wl.tolist()
+    err = float((out.cpu().double() - want).abs().max())
+    assert err <= ENC_TOL, err
+
+
+def test_post_attention_kernel_vs_fp64(pkg):
+    """The fused kernel behind attention (output projection + FSMN + residual, norm2, feed-forward, next-layer
+    normalisation) on its own, through the debug hook: x_out within 2e-3 and the normalised y within 1e-2 of an
+    fp64 evaluation on the same 16-bit-rounded inputs; row counts around the 32 / 128 row tile edges."""
+    import ctypes as C
+    cfg = so.SanmConfig(num_blocks=2)
+    sd = _trained_like(so.make_state_dict(cfg, seed=4, dtype=torch.float32), seed=6)
+    enc = pkg.SANMEncoder(num_blocks=2)
+    enc.load_state_dict(sd)
+    ctx = enc.ctx
+    stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    w = {k: v.double().cuda() for k, v in sd.items()}
+    p = "encoders0.0."
+    for m, with_x in [(1, True), (31, False), (32, True), (129, True), (257, False), (1000, True)]:
+        gen = torch.Generator().manual_seed(m)
+        att = (torch.randn(m, 512, generator=gen) * 0.5).half().cuda()
+        fsmn = (torch.randn(m, 512, generator=gen) * 0.5).half().cuda()
+        x = (torch.randn(m, 512, generator=gen) * 2.0 + 0.3).cuda()
+        xo = torch.empty_like(x)
+        y = torch.empty(m, 512, dtype=torch.float16, device="cuda")
+        ctx.check(ctx.lib.asrfe_debug_post_attn(ctx.handle, 0, att.data_ptr(), fsmn.data_ptr(),
+                                                x.data_ptr() if with_x else None, xo.data_ptr(), y.data_ptr(), m, 0, stream))
+        xm = att.double() @ w[p + "self_attn.linear_out.weight"].T + w[p + "self_attn.linear_out.bias"] + fsmn.double()
+        if with_x:
+            xm = xm + x.double()
+        hh = torch.nn.functional.layer_norm(xm, (512,), w[p + "norm2.weight"], w[p + "norm2.bias"], 1e-12)
+        hh = torch.relu(hh @ w[p + "feed_forward.w_1.weight"].T + w[p + "feed_forward.w_1.bias"])
+        ref = xm + hh @ w[p + "feed_forward.w_2.weight"].T + w[p + "feed_forward.w_2.bias"]
+        yref = torch.nn.functional.layer_norm(ref, (512,), None, None, 1e-12)
+        assert float((xo.double() - ref).abs().max()) <= 2e-3, (m, with_x)
+        assert float((y.double() - yref).abs().max()) <= 1e-2, (m, with_x)
+
+
+def test_fused_and_unfused_encoder_paths_agree(pkg, monkeypatch):
+    """ASRFE_UNFUSED_FFN=1 selects separate LayerNorm / GEMM launches for the same layer: both paths must meet the
+    parity bar and stay within 2e-3 of each other."""
+    cfg = so.SanmConfig(num_blocks=2)
+    sd = _trained_like(so.make_state_dict(cfg, seed=12, dtype=torch.float32), seed=13)
+    lens = torch.tensor([130, 77], dtype=torch.int32)
+    feats = so.synth_feats(2, 130, 560, seed=8)
+    outs = []
+    for flag in ("0", "1"):
+        monkeypatch.setenv("ASRFE_UNFUSED_FFN", flag)
+        enc = pkg.SANMEncoder(num_blocks=2)
+        enc.load_state_dict(sd)
+        out, _, _ = enc.forward(feats.cuda(), lens)
+        outs.append(out.cpu())
+    want, _ = so.encoder_forward(feats, lens, sd, cfg)
+    assert float((outs[0] - want).abs().max()) <= ENC_TOL
+    assert float((outs[1] - want).abs().max()) <= ENC_TOL
+    assert float((outs[0] - outs[1]).abs().max()) <= 2e-3
