@@ -28,6 +28,7 @@
 #include "common.h"
 #include "elem.h"
 #include "gemm.h"
+#include "lds_dma.h"
 
 namespace asrfe {
 
@@ -38,16 +39,17 @@ constexpr int kSlotBytes = 4 * kHalfBytes;   // A0 | A1 | B0 | B1
 constexpr int kRingBytes = 2 * kSlotBytes;   // 128 KiB
 constexpr int kGemmLds = kRingBytes + 8 * 4096;  // + one 4 KiB epilogue slab per wave = 160 KiB
 
-#define GLDS16(gptr, lptr)                                                                         \
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gptr),       \
-                                     (__attribute__((address_space(3))) void*)(lptr), 16, 0, 0)
-
-// End of a phase: this wave's loads for the next phase have landed and its LDS reads are done, then all
-// waves meet.  One asm statement, so nothing is scheduled between the wait and the barrier.
+// End of a phase: this wave's loads for the next phase have landed, then all waves meet.  One asm statement,
+// so nothing is scheduled between the wait and the barrier.  The LDS-DMA loads are issued through inline
+// assembly (lds_dma.h), so the compiler keeps COUNTED lgkmcnt waits for the fragment reads: a fragment read
+// issued in one phase is waited for only where its MFMA needs it, not at the phase boundary.  A half-tile
+// is refilled after this barrier while reads of it issued just before the barrier may not have returned yet;
+// they are already queued in the LDS pipeline, which serves one wave's requests in order and receives the DMA
+// data only a global-memory round trip later.
 #define PHASE_SYNC(steady)                                                                         \
     do {                                                                                           \
-        if (steady) asm volatile("s_waitcnt vmcnt(10) lgkmcnt(0)\n\ts_barrier" ::: "memory");     \
-        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");             \
+        if (steady) asm volatile("s_waitcnt vmcnt(10)\n\ts_barrier" ::: "memory");                \
+        else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");                        \
     } while (0)
 
 // 16-byte global store with a selectable cache policy: 0 plain, 1 non-temporal, 2 write-through (sc1)
@@ -223,15 +225,16 @@ __global__ __launch_bounds__(kGemmThreads) void gemm_bf16_kernel(const GemmParam
         }
     };
     // half: 0 A0, 1 A1, 2 B0, 3 B1
+    const uint32_t smem_base = __builtin_amdgcn_readfirstlane(lds_addr_of(smem));
     auto stage = [&](int half, int slot) {
-        char* dst = smem + slot * kSlotBytes + half * kHalfBytes + wave_slot;
+        const uint32_t dst = __builtin_amdgcn_readfirstlane(smem_base + slot * kSlotBytes + half * kHalfBytes + wave_slot);
         const int kb = st_kt * (BK * 2);
         if (half < 2) {
-            GLDS16(a_tile + aoff[half][0] + kb, dst);
-            GLDS16(a_tile + aoff[half][1] + kb, dst + 8192);
+            lds_dma16(a_tile + kb, aoff[half][0], dst);
+            lds_dma16(a_tile + kb, aoff[half][1], dst + 8192);
         } else {
-            GLDS16(w_tile + boff[half - 2][0] + kb, dst);
-            GLDS16(w_tile + boff[half - 2][1] + kb, dst + 8192);
+            lds_dma16(w_tile + kb, boff[half - 2][0], dst);
+            lds_dma16(w_tile + kb, boff[half - 2][1], dst + 8192);
         }
     };
 
@@ -279,19 +282,16 @@ __global__ __launch_bounds__(kGemmThreads) void gemm_bf16_kernel(const GemmParam
     // the K-tile two ahead (if it exists).
 #define PHASE(A_, B_, STAGE_HALF, STAGE_SLOT, FREE_B, FREE_SLOT, ROLL_A, ROLL_SLOT, SYNC, STEADY)            \
     do {                                                                                                    \
-        if ((STEADY) && !no_stage) stage(STAGE_HALF, STAGE_SLOT);                                           \
-        if (FREE_B >= 0 && !no_read) read_b(FREE_B < 0 ? 0 : FREE_B, FREE_SLOT);                            \
+        if (STEADY) stage(STAGE_HALF, STAGE_SLOT);                                           \
+        if (FREE_B >= 0) read_b(FREE_B < 0 ? 0 : FREE_B, FREE_SLOT);                            \
         _Pragma("unroll") for (int s = 0; s < 4; ++s) {                                                     \
             _Pragma("unroll") for (int ms = 0; ms < 2; ++ms) {                                              \
                 acc[B_][(A_) * 2 + ms] = mfma32<F16>(rb[B_][s], ra[ms][s], acc[B_][(A_) * 2 + ms]);         \
-                if (ROLL_A >= 0 && !no_read) read_a(ROLL_A < 0 ? 0 : ROLL_A, ROLL_SLOT, ms, s);             \
+                if (ROLL_A >= 0) read_a(ROLL_A < 0 ? 0 : ROLL_A, ROLL_SLOT, ms, s);             \
             }                                                                                               \
         }                                                                                                   \
-        if ((SYNC) && !no_sync) PHASE_SYNC(STEADY);                                                         \
+        if (SYNC) PHASE_SYNC(STEADY);                                                         \
     } while (0)
-
-    // timing experiments only (results are wrong when any of these is set)
-    const bool no_stage = p.flags & 2, no_sync = p.flags & 4, no_read = p.flags & 8;
 
     // ---- prologue: the first two K-tiles in flight, then the first fragments
     stage_set_tile();

@@ -1,0 +1,23 @@
+// 16-byte LDS-DMA loads (global memory -> LDS without a register round trip) for gfx950.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace asrfe {
+
+// LDS[lds_addr + 16 * lane] = *(sbase + voff): scalar 64-bit base, unsigned 32-bit per-lane byte offset.
+// Issued through inline assembly on purpose: the compiler models a load that touches both global memory and
+// LDS as a flat access and, while one is pending, turns every wait it inserts into vmcnt(0) / lgkmcnt(0); hidden
+// from it, its own LDS-read waits stay counted.  The kernel orders these loads itself with counted
+// s_waitcnt vmcnt(N) (loads complete in issue order).
+__device__ __forceinline__ void lds_dma16(const void* sbase, uint32_t voff, uint32_t lds_addr) {
+    asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(lds_addr), "v"(voff), "s"(sbase) : "memory");
+}
+
+// LDS byte address of a pointer into a __shared__ array
+__device__ __forceinline__ uint32_t lds_addr_of(const void* p) {
+    return static_cast<uint32_t>(reinterpret_cast<uintptr_t>((const __attribute__((address_space(3))) char*)p));
+}
+
+}  // namespace asrfe

@@ -40,6 +40,7 @@
 #include "common.h"
 #include "elem.h"
 #include "encoder.h"
+#include "lds_dma.h"
 
 namespace asrfe {
 
@@ -51,17 +52,6 @@ constexpr int kFfnThreads = 256;
 constexpr int kFfnRows = 128;
 constexpr int kPieceBytes = 16384;
 constexpr int kFfnRing = 8 * kPieceBytes;  // 128 KiB; the fp32 b1, b2 and b_o vectors follow it
-
-// 16-byte LDS-DMA load: LDS[m0 + 16 * lane] = *(sbase + voff) (scalar base, 32-bit per-lane offset).  Issued through inline assembly on purpose: the compiler
-// models a load that touches both global memory and LDS as a flat access and, while one is pending, turns
-// every wait it inserts into vmcnt(0) / lgkmcnt(0); hidden from it, its LDS-read waits stay counted.  The
-// kernel orders these loads itself (wait_vm_barrier).
-__device__ __forceinline__ void ffn_glds16(const void* sbase, uint32_t voff, uint32_t lds_addr) {
-    asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(lds_addr), "v"(voff), "s"(sbase) : "memory");
-}
-__device__ __forceinline__ uint32_t lds_addr_of(const void* p) {
-    return static_cast<uint32_t>(reinterpret_cast<uintptr_t>((const __attribute__((address_space(3))) char*)p));
-}
 
 template <int I>
 using IC = std::integral_constant<int, I>;
@@ -78,7 +68,11 @@ __device__ __forceinline__ void static_for(Fn&& f) {
 // all but the N youngest vector-memory operations of this wave are done, then every wave of the workgroup meets
 template <int N>
 __device__ __forceinline__ void wait_vm_barrier() {
+#if ASRFE_FFN_TIMING == 2  // timing experiment: no workgroup barrier (wrong results)
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+#else
     asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(N) : "memory");
+#endif
 }
 
 __device__ __forceinline__ void ffn_wave_lds_sync() {
@@ -179,7 +173,7 @@ __global__ __launch_bounds__(kFfnThreads) void post_attn_kernel(const FfnParams 
     auto stage_quarter = [&](auto rc, const char* cbase, int i) {
         constexpr int R = decltype(rc)::value;
         const uint32_t dst = __builtin_amdgcn_readfirstlane(smem_base + R * kPieceBytes + wave * 1024);
-        ffn_glds16(cbase + R * kPieceBytes + i * 4096, wlane, dst + i * 4096);
+        lds_dma16(cbase + R * kPieceBytes + i * 4096, wlane, dst + i * 4096);
     };
     // chunk c of the layer's stream: 0..3 are Wo, 4 + j is hidden chunk j
     auto chunk_base = [&](int c) { return wsrc + static_cast<int64_t>(c) * (8 * kPieceBytes); };
@@ -228,14 +222,14 @@ __global__ __launch_bounds__(kFfnThreads) void post_attn_kernel(const FfnParams 
             const uint32_t dst = xs_lds + (I & 3) * 4096;
             if constexpr (I < 8) {
 #pragma unroll
-                for (int k = 0; k < 4; ++k) ffn_glds16(asrc + I * 128, aoff[k], dst + k * 1024);
+                for (int k = 0; k < 4; ++k) lds_dma16(asrc + I * 128, aoff[k], dst + k * 1024);
             } else if constexpr ((I - 8) % 3 == 0) {
 #pragma unroll
-                for (int k = 0; k < 4; ++k) ffn_glds16(fsrc + ((I - 8) / 3) * 128, aoff[k], dst + k * 1024);
+                for (int k = 0; k < 4; ++k) lds_dma16(fsrc + ((I - 8) / 3) * 128, aoff[k], dst + k * 1024);
             } else {
                 constexpr int nt = 2 * ((I - 8) / 3) + ((I - 8) % 3 - 1);
 #pragma unroll
-                for (int k = 0; k < 4; ++k) ffn_glds16(xsrc + nt * 128, xoff[k], dst + k * 1024);
+                for (int k = 0; k < 4; ++k) lds_dma16(xsrc + nt * 128, xoff[k], dst + k * 1024);
             }
         };
         slab_dma(IC<0>{}); slab_dma(IC<1>{}); slab_dma(IC<2>{}); slab_dma(IC<3>{});
