@@ -385,3 +385,22 @@ def test_fused_and_unfused_encoder_paths_agree(pkg, monkeypatch):
     assert float((outs[0] - want).abs().max()) <= ENC_TOL
     assert float((outs[1] - want).abs().max()) <= ENC_TOL
     assert float((outs[0] - outs[1]).abs().max()) <= 2e-3
+
+
+def test_engine_streams_give_identical_results(pkg):
+    """Two chunks on two HIP streams, and the single-stream run of the same engine, are bit-identical."""
+    n = 16000 * 4
+    clips = np.stack([fo.synth_pcm(k, n, 80 + i) for i, k in enumerate(["bursts", "gauss", "chirp", "uniform", "bench"])])
+    lens = dev(np.array([64000, 50000, 16000, 700, 33333], np.int32))
+    sd = so.make_state_dict(so.SanmConfig(num_blocks=2), seed=3)
+    cfg = pkg.default_config()
+    cfg.enc_num_blocks = 2
+    e2 = pkg.AsrEngine(batch=5, max_samples=n, cfg=cfg, state_dict=sd, n_streams=2)
+    out2 = e2.run(dev(clips), lens)[0].clone()
+    out1 = e2.run_single_stream(dev(clips), lens)[0].clone()
+    torch.cuda.synchronize()
+    assert torch.equal(out1, out2)
+    e1 = pkg.AsrEngine(batch=5, max_samples=n, cfg=cfg, state_dict=sd, n_streams=1)
+    out0 = e1.run(dev(clips), lens)[0]
+    torch.cuda.synchronize()
+    assert torch.equal(out0, out2)

@@ -113,6 +113,24 @@ class AsrEngine:
         for ev in self._done:
             cur.wait_event(ev)
 
+    def run_single_stream(self, pcm: torch.Tensor, pcm_lens: torch.Tensor):
+        """The same step as ``run`` on the current stream only, whatever ``n_streams`` is (per-kernel timing wants
+        the launches back to back on one stream).  Its full-batch workspace is allocated on first use."""
+        if len(self.chunks) == 1:
+            return self.run(pcm, pcm_lens)
+        if not hasattr(self, "_ws_full"):
+            nbytes = self.encoder.workspace_bytes(self.batch, self.tp_max)
+            buf = torch.empty((nbytes + 256,), dtype=torch.uint8, device=self.device)
+            self._ws_full = (buf, (buf.data_ptr() + 255) // 256 * 256, nbytes)
+        dt = self._check_pcm(pcm, pcm_lens)
+        st = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        self._frontend_chunk(pcm, pcm_lens, dt, 0, self.batch, st)
+        _, ptr, nbytes = self._ws_full
+        self.ctx.check(self.ctx.lib.asrfe_encoder_forward(
+            self.ctx.handle, self.feats.data_ptr(), self.feat_lens.data_ptr(), self.batch, self.tp_max,
+            self.out.data_ptr(), self.out_dtype, ptr, nbytes, st))
+        return self.out, self.feat_lens
+
     def run_frontend(self, pcm: torch.Tensor, pcm_lens: torch.Tensor):
         """pcm [batch, >= max len] int16/float32 and pcm_lens [batch] int32, both on this device."""
         self._run(pcm, pcm_lens, True, False)
