@@ -7,13 +7,14 @@
 //   row sum are register reductions plus one exchange with lane ^ 32, and the probabilities are
 //   already laid out as the B operand of the second product O^T = V^T P^T, whose accumulator again has
 //   the query on the lane, so the running rescale is a per-lane scalar.
-//   K tiles go global -> LDS by 16-byte LDS-DMA loads with the bank swizzle on the source address
+//   K tiles go global -> LDS by 16-byte LDS-DMA loads (lds_dma.h) with the bank swizzle on the source address
 //   (chunk c of key row r sits at chunk c ^ (r & 15)); V arrives pre-transposed ([d][t], written by the
 //   FSMN kernel) and is register-staged into rows padded to 136 bytes so that the 8-byte fragment
 //   reads of 32 lanes hit 32 different bank pairs.
 #include "common.h"
 #include "elem.h"
 #include "encoder.h"
+#include "lds_dma.h"
 
 namespace asrfe {
 
@@ -21,10 +22,6 @@ constexpr int kAttnThreads = 256;
 constexpr int kKTileBytes = 64 * 256;      // 64 keys x 128 d bf16
 constexpr int kVRow = 136;                 // bytes per V^T row (64 keys bf16 + 8 pad)
 constexpr int kVTileBytes = 128 * kVRow;
-
-#define GLDS16(gptr, lptr)                                                                         \
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gptr),       \
-                                     (__attribute__((address_space(3))) void*)(lptr), 16, 0, 0)
 
 template <bool F16>
 __global__ __launch_bounds__(kAttnThreads, 2) void attn_kernel(const AttnParams p) {
@@ -55,15 +52,17 @@ __global__ __launch_bounds__(kAttnThreads, 2) void attn_kernel(const AttnParams 
     const int v_row = tid >> 3;                                   // + 32 i
     const int v_chunk = tid & 7;
     const uint16_t* vbase = p.vt + (static_cast<int64_t>(b) * 512 + head * 128) * p.Tk;
-    const uint16_t* kbase = p.qkv + 512 + head * 128 + k_chunk * 8;
+    // K tile source: scalar base (this utterance, this head) + per-lane byte offset (key row, swizzled chunk)
+    const char* kbase = reinterpret_cast<const char*>(p.qkv + row0 * p.ld_qkv + 512 + head * 128);
+    const uint32_t smem_base = __builtin_amdgcn_readfirstlane(lds_addr_of(smem));
 
     auto k_issue = [&](int kt, int buf) {
-        char* ks = smem + buf * (kKTileBytes + kVTileBytes);
+        const uint32_t ks = __builtin_amdgcn_readfirstlane(smem_base + buf * (kKTileBytes + kVTileBytes) + wave * 1024);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             int key = kt * 64 + i * 16 + k_row;
             key = key < p.Tp ? key : p.Tp - 1;
-            GLDS16(kbase + (row0 + key) * p.ld_qkv, ks + i * 4096 + wave * 1024);
+            lds_dma16(kbase, static_cast<uint32_t>(key) * static_cast<uint32_t>(p.ld_qkv * 2) + k_chunk * 16, ks + i * 4096);
         }
     };
     uint4 vreg[4];
@@ -107,8 +106,10 @@ __global__ __launch_bounds__(kAttnThreads, 2) void attn_kernel(const AttnParams 
 
     for (int kt = 0; kt < n_kt; ++kt) {
         const int cur = kt & 1;
-        // tile kt is complete in LDS (the barrier's fence drains this thread's LDS-DMA loads and LDS writes) and
-        // every wave is done with tile kt - 1, whose buffer is refilled below
+        // tile kt is complete in LDS (this thread's LDS-DMA loads are drained by hand: they are issued through
+        // inline assembly, which keeps the compiler's LDS-read waits counted; its LDS writes by the barrier's fence)
+        // and every wave is done with tile kt - 1, whose buffer is refilled below
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         const bool more = kt + 1 < n_kt;
         if (more) {
