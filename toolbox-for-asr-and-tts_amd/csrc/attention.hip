@@ -1,16 +1,24 @@
-// Masked multi-head self-attention for the SAN-M encoder (d_k = 128) on gfx950, flash style.
+// Masked multi-head self-attention (d_k = 128) and the FSMN memory block of the SAN-M encoder on gfx950.
 //
-//   One workgroup = 4 waves = 128 query rows of one (utterance, head); each wave owns 32 query rows
-//   and walks the key axis in tiles of 64 with an online softmax.
-//   Scores are computed transposed, S^T = K Q^T (v_mfma_f32_32x32x16_bf16 with the K tile as the A
-//   operand and Q as the B operand), so a lane holds 32 key scores of ONE query row: the row max and
-//   row sum are register reductions plus one exchange with lane ^ 32, and the probabilities are
-//   already laid out as the B operand of the second product O^T = V^T P^T, whose accumulator again has
-//   the query on the lane, so the running rescale is a per-lane scalar.
-//   K tiles go global -> LDS by 16-byte LDS-DMA loads (lds_dma.h) with the bank swizzle on the source address
-//   (chunk c of key row r sits at chunk c ^ (r & 15)); V arrives pre-transposed ([d][t], written by the
-//   FSMN kernel) and is register-staged into rows padded to 136 bytes so that the 8-byte fragment
-//   reads of 32 lanes hit 32 different bank pairs.
+//   One workgroup = 4 waves = 128 query rows of one (utterance, head).
+//
+//   FSMN first: fsmn[t][c] = mask_t (v_m[t][c] + sum_j w[j][c] v_m[t + j - 5][c]) for the workgroup's 128 rows and
+//   its head's 128 channels (v_m = v inside the utterance, else 0).  The 128 + 2 x 5 rows of V it needs are
+//   brought into LDS by LDS-DMA; a thread owns a pair of channels and 32 consecutive rows and slides an 11-tap
+//   window through registers, so a wave stores whole 256-byte rows.
+//
+//   Attention, flash style: each wave owns 32 query rows and walks the key axis in tiles of 64 with an online
+//   softmax.  Scores are computed transposed, S^T = K Q^T (v_mfma_f32_32x32x16 with the K tile as the A operand
+//   and Q as the B operand), so a lane holds 32 key scores of ONE query row: the row max and row sum are
+//   register reductions plus one exchange with lane ^ 32, and the probabilities are already laid out as the B
+//   operand of the second product O^T = V^T P^T, whose accumulator again has the query on the lane, so the
+//   running rescale is a per-lane scalar.
+//   K and V tiles ([64 keys][128 d], 256-byte rows) go global -> LDS by 16-byte LDS-DMA loads (lds_dma.h) with
+//   the bank swizzle on the source address: K chunk c of row r sits at chunk c ^ (r & 15) (row reads,
+//   ds_read_b128); V chunk c of row r sits at chunk c ^ (((r & 3) << 2) | ((r >> 2) & 3)) and is read
+//   TRANSPOSED by ds_read_b64_tr_b16: a 16-lane group fetches a block of 4 keys x 16 channels and every lane
+//   receives the 4 keys of one channel, which is the A operand of O^T = V^T P^T.  No transposed copy of V exists
+//   in memory.  Keys at or past the utterance length get probability 0 (their V rows are finite, so 0 x V = 0).
 #include "common.h"
 #include "elem.h"
 #include "encoder.h"
@@ -19,14 +27,19 @@
 namespace asrfe {
 
 constexpr int kAttnThreads = 256;
-constexpr int kKTileBytes = 64 * 256;      // 64 keys x 128 d bf16
-constexpr int kVRow = 136;                 // bytes per V^T row (64 keys bf16 + 8 pad)
-constexpr int kVTileBytes = 128 * kVRow;
+constexpr int kTileBytes = 64 * 256;       // 64 keys x 128 d, 16-bit
+constexpr int kBufBytes = 2 * kTileBytes;  // K tile | V tile
+constexpr int kFsmnHalo = 5;
+constexpr int kFsmnTaps = 11;
+static_assert(kTileBytes + 9 * 4096 <= 2 * kBufBytes, "FSMN stage (9 DMA rounds of 16 rows = 128 + 2 x 5 halo rows, rounded up) fits behind K tile 0");
+
+typedef short v4s __attribute__((ext_vector_type(4)));
 
 template <bool F16>
 __global__ __launch_bounds__(kAttnThreads, 2) void attn_kernel(const AttnParams p) {
-    // two K/V buffers: tile kt + 1 is fetched while tile kt is multiplied
-    __shared__ __attribute__((aligned(16))) char smem[2 * (kKTileBytes + kVTileBytes)];
+    // two K/V buffers: tile kt + 1 is fetched while tile kt is multiplied.  The FSMN phase stages its rows in
+    // bytes [16 KiB, 52 KiB) while K tile 0 already flies into [0, 16 KiB).
+    __shared__ __attribute__((aligned(16))) char smem[2 * kBufBytes];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -42,49 +55,99 @@ __global__ __launch_bounds__(kAttnThreads, 2) void attn_kernel(const AttnParams 
     const int b = logical / (p.n_qtiles * 4);
     int len = p.lens[b];
     len = len < 0 ? 0 : (len > p.Tp ? p.Tp : len);
-    const int q0 = qtile * 128 + wave * 32;
+    const int qb = qtile * 128;          // first query row of the workgroup
+    const int q0 = qb + wave * 32;       // first query row of the wave
     const int64_t row0 = static_cast<int64_t>(b) * p.Tp;
     const int n_kt = (len + 63) >> 6;
+    const uint32_t ldb = static_cast<uint32_t>(p.ld_qkv) * 2;  // bytes per qkv row
 
-    // staging addresses
-    const int k_row = tid >> 4;                                   // + 16 i
-    const int k_chunk = (tid & 15) ^ ((tid >> 4) & 15);           // source chunk for LDS slot (row, tid & 15)
-    const int v_row = tid >> 3;                                   // + 32 i
-    const int v_chunk = tid & 7;
-    const uint16_t* vbase = p.vt + (static_cast<int64_t>(b) * 512 + head * 128) * p.Tk;
-    // K tile source: scalar base (this utterance, this head) + per-lane byte offset (key row, swizzled chunk)
-    const char* kbase = reinterpret_cast<const char*>(p.qkv + row0 * p.ld_qkv + 512 + head * 128);
+    // ---- tile staging: thread covers LDS slot (row i * 16 + (tid >> 4), chunk tid & 15) of a tile, i = 0..3
     const uint32_t smem_base = __builtin_amdgcn_readfirstlane(lds_addr_of(smem));
-
-    auto k_issue = [&](int kt, int buf) {
-        const uint32_t ks = __builtin_amdgcn_readfirstlane(smem_base + buf * (kKTileBytes + kVTileBytes) + wave * 1024);
+    const char* kbase = reinterpret_cast<const char*>(p.qkv + row0 * p.ld_qkv + 512 + head * 128);
+    const char* vbase = reinterpret_cast<const char*>(p.qkv + row0 * p.ld_qkv + 1024 + head * 128);
+    const int st_row = tid >> 4;
+    const uint32_t k_chunk = (tid & 15) ^ ((tid >> 4) & 15);
+    const uint32_t v_chunk = (tid & 15) ^ ((((tid >> 4) & 3) << 2) | ((tid >> 6) & 3));
+    auto kv_issue = [&](int kt, int buf, bool with_v) {
+        const uint32_t dst = __builtin_amdgcn_readfirstlane(smem_base + buf * kBufBytes + wave * 1024);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            int key = kt * 64 + i * 16 + k_row;
+            int key = kt * 64 + i * 16 + st_row;
             key = key < p.Tp ? key : p.Tp - 1;
-            lds_dma16(kbase, static_cast<uint32_t>(key) * static_cast<uint32_t>(p.ld_qkv * 2) + k_chunk * 16, ks + i * 4096);
+            const uint32_t ro = static_cast<uint32_t>(key) * ldb;
+            lds_dma16(kbase, ro + k_chunk * 16, dst + i * 4096);
+            if (with_v) lds_dma16(vbase, ro + v_chunk * 16, dst + kTileBytes + i * 4096);
         }
     };
-    uint4 vreg[4];
-    auto v_load = [&](int kt) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-            vreg[i] = *reinterpret_cast<const uint4*>(vbase + static_cast<int64_t>(i * 32 + v_row) * p.Tk + kt * 64 + v_chunk * 8);
-    };
-    auto v_store = [&](int buf) {
-        char* vs = smem + buf * (kKTileBytes + kVTileBytes) + kKTileBytes;
+    auto v_issue = [&](int kt, int buf) {
+        const uint32_t dst = __builtin_amdgcn_readfirstlane(smem_base + buf * kBufBytes + kTileBytes + wave * 1024);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            uint2* dst = reinterpret_cast<uint2*>(vs + (i * 32 + v_row) * kVRow + v_chunk * 16);
-            dst[0] = make_uint2(vreg[i].x, vreg[i].y);
-            dst[1] = make_uint2(vreg[i].z, vreg[i].w);
+            int key = kt * 64 + i * 16 + st_row;
+            key = key < p.Tp ? key : p.Tp - 1;
+            lds_dma16(vbase, static_cast<uint32_t>(key) * ldb + v_chunk * 16, dst + i * 4096);
         }
     };
 
-    if (n_kt > 0) {
-        k_issue(0, 0);
-        v_load(0);
+    if (n_kt > 0) kv_issue(0, 0, false);  // K tile 0; V tile 0 follows the FSMN phase (its buffer is the FSMN stage)
+
+    // ---- FSMN memory block for rows qb .. qb + 127 of this head -----------------------------------------------
+    {
+        // stage row rr (0..143) = V row qb - 5 + rr, clamped into the utterance's rows (masked when used)
+        const uint32_t fst = __builtin_amdgcn_readfirstlane(smem_base + kTileBytes + wave * 1024);
+#pragma unroll
+        for (int i = 0; i < 9; ++i) {
+            int t = qb - kFsmnHalo + i * 16 + st_row;
+            t = t < 0 ? 0 : (t > p.Tp - 1 ? p.Tp - 1 : t);
+            lds_dma16(vbase, static_cast<uint32_t>(t) * ldb + (tid & 15) * 16, fst + i * 4096);
+        }
+        // taps of this thread's two channels
+        const int cp = tid & 63, rg = tid >> 6;  // channel pair, group of 32 rows
+        float w0[kFsmnTaps], w1[kFsmnTaps];
+#pragma unroll
+        for (int j = 0; j < kFsmnTaps; ++j) {
+            const float2 w = *reinterpret_cast<const float2*>(p.w_fsmn + j * 512 + head * 128 + 2 * cp);
+            w0[j] = w.x;
+            w1[j] = w.y;
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        const char* fs = smem + kTileBytes + (32 * rg) * 256 + 4 * cp;
+        float x0[kFsmnTaps], x1[kFsmnTaps];  // window: x[j] = v_m[t + j - 5]
+#pragma unroll
+        for (int j = 0; j < kFsmnTaps - 1; ++j) {
+            const int tt = qb + 32 * rg + j - kFsmnHalo;  // time of stage row 32 rg + j
+            const uint32_t raw = *reinterpret_cast<const uint32_t*>(fs + j * 256);
+            unpack_elem2<F16>(raw, x0[j + 1], x1[j + 1]);
+            if (tt < 0 || tt >= len) x0[j + 1] = x1[j + 1] = 0.0f;
+        }
+        uint32_t* out = reinterpret_cast<uint32_t*>(p.fsmn + (row0 + qb + 32 * rg) * 512 + head * 128 + 2 * cp);
+#pragma unroll
+        for (int i = 0; i < 32; ++i) {
+            const int t = qb + 32 * rg + i;
+#pragma unroll
+            for (int j = 0; j < kFsmnTaps - 1; ++j) {
+                x0[j] = x0[j + 1];
+                x1[j] = x1[j + 1];
+            }
+            {
+                const int tt = t + kFsmnHalo;
+                const uint32_t raw = *reinterpret_cast<const uint32_t*>(fs + (i + kFsmnTaps - 1) * 256);
+                unpack_elem2<F16>(raw, x0[kFsmnTaps - 1], x1[kFsmnTaps - 1]);
+                if (tt >= len) x0[kFsmnTaps - 1] = x1[kFsmnTaps - 1] = 0.0f;
+            }
+            float a0 = x0[kFsmnHalo], a1 = x1[kFsmnHalo];
+#pragma unroll
+            for (int j = 0; j < kFsmnTaps; ++j) {
+                a0 = fmaf(w0[j], x0[j], a0);
+                a1 = fmaf(w1[j], x1[j], a1);
+            }
+            if (t < p.Tp) out[static_cast<int64_t>(i) * 256] = t < len ? pack_elem2<F16>(a0, a1) : 0u;
+        }
+        __syncthreads();  // the stage is consumed: its bytes become V tile 0 / K, V tile 1
     }
+    if (n_kt > 0) v_issue(0, 0);
+
     // Q fragments: lane holds Q[q0 + l31][16 s + 8 h .. +8), s = 0..7
     u16x8 qf[8];
     {
@@ -93,8 +156,26 @@ __global__ __launch_bounds__(kAttnThreads, 2) void attn_kernel(const AttnParams 
         const uint16_t* qp = p.qkv + (row0 + qr) * p.ld_qkv + head * 128 + 8 * h;
 #pragma unroll
         for (int s = 0; s < 8; ++s) qf[s] = *reinterpret_cast<const u16x8*>(qp + 16 * s);
+        // Use the fragments once here: the compiler then waits for these loads before the loop.  Left to their first
+        // use inside the loop, its vmcnt waits there would also drain the K / V prefetch it does not know about.
+#pragma unroll
+        for (int s = 0; s < 8; ++s) asm volatile("" : "+v"(qf[s]));
     }
-    if (n_kt > 0) v_store(0);
+
+    // transposed V reads: lane 4 q + pp of a 16-lane group addresses key row q of the 4-key block, channels
+    // 4 pp .. 4 pp + 3 of the group's 16; groups 0, 1 (h = 0) and 2, 3 (h = 1) take keys 4 h .. 4 h + 3 of each 8.
+    // Row r = 16 n + 8 hi + 4 h + q keeps chunk c at c ^ ((q << 2) | (2 hi + h)): the low bits are folded here.
+    int vtr[4][2];
+    {
+        const int q = (lane >> 2) & 3, pp = lane & 3, g1 = (lane >> 4) & 1;
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int hi = 0; hi < 2; ++hi) {
+                const int chunk = ((mt ^ q) << 2) | ((2 * g1 + (pp >> 1)) ^ (2 * hi + h));
+                vtr[mt][hi] = (8 * hi + 4 * h + q) * 256 + chunk * 16 + 8 * (pp & 1);
+            }
+    }
 
     f32x16 oacc[4];
 #pragma unroll
@@ -107,17 +188,13 @@ __global__ __launch_bounds__(kAttnThreads, 2) void attn_kernel(const AttnParams 
     for (int kt = 0; kt < n_kt; ++kt) {
         const int cur = kt & 1;
         // tile kt is complete in LDS (this thread's LDS-DMA loads are drained by hand: they are issued through
-        // inline assembly, which keeps the compiler's LDS-read waits counted; its LDS writes by the barrier's fence)
-        // and every wave is done with tile kt - 1, whose buffer is refilled below
+        // inline assembly, which keeps the compiler's LDS-read waits counted) and every wave is done with tile
+        // kt - 1, whose buffer is refilled below
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        const bool more = kt + 1 < n_kt;
-        if (more) {
-            k_issue(kt + 1, cur ^ 1);
-            v_load(kt + 1);
-        }
-        const char* ks = smem + cur * (kKTileBytes + kVTileBytes);
-        const char* vs = ks + kKTileBytes;
+        if (kt + 1 < n_kt) kv_issue(kt + 1, cur ^ 1, true);
+        const char* ks = smem + cur * kBufBytes;
+        const char* vs = ks + kTileBytes;
 
         // ---- S^T = K Q^T : two 32-key sub-tiles ---------------------------------------------
         f32x16 sacc[2];
@@ -175,19 +252,20 @@ __global__ __launch_bounds__(kAttnThreads, 2) void attn_kernel(const AttnParams 
         // ---- O^T += V^T P^T ----------------------------------------------------------------------
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt) {
-            const char* vrow = vs + (mt * 32 + l31) * kVRow + 8 * h;
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
                 for (int s2 = 0; s2 < 2; ++s2) {
                     // element j of the fragment is key 32 kk + 16 s2 + 8 (j >> 2) + 4 h + (j & 3)
-                    const u16x4 lo = *reinterpret_cast<const u16x4*>(vrow + (kk * 32 + s2 * 16) * 2);
-                    const u16x4 hi = *reinterpret_cast<const u16x4*>(vrow + (kk * 32 + s2 * 16 + 8) * 2);
-                    const u16x8 vf = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+                    const char* blk = vs + (kk * 32 + s2 * 16) * 256;
+                    const v4s lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                        (__attribute__((address_space(3))) v4s*)(blk + vtr[mt][0]));
+                    const v4s hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                        (__attribute__((address_space(3))) v4s*)(blk + vtr[mt][1]));
+                    const u16x8 vf = __builtin_bit_cast(u16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
                     oacc[mt] = mfma32<F16>(vf, pf[kk][s2], oacc[mt]);
                 }
         }
-        if (more) v_store(cur ^ 1);
     }
 
     // ---- normalise; each wave routes its 32 x 128 tile through LDS so that 16 lanes store one full 256-byte row ----
@@ -222,7 +300,9 @@ __global__ __launch_bounds__(kAttnThreads, 2) void attn_kernel(const AttnParams 
 
 int32_t launch_attention(asrfe_ctx* ctx, const AttnParams& p, hipStream_t s) {
     if (p.B <= 0 || p.Tp <= 0) return ASRFE_OK;
-    if (p.Tk % 64 != 0 || p.Tk < p.Tp) return set_err(ctx, ASRFE_ERR_SHAPE, "attention: Tk must be Tp rounded up to 64");
+    if (!p.qkv || !p.lens || !p.out || !p.fsmn || !p.w_fsmn) return set_err(ctx, ASRFE_ERR_BAD_ARG, "attention: null argument");
+    if (static_cast<int64_t>(p.Tp) * p.ld_qkv * 2 >= (int64_t{1} << 32))
+        return set_err(ctx, ASRFE_ERR_SHAPE, "attention: one utterance's qkv rows must stay below 4 GiB");
     AttnParams q = p;
     q.n_qtiles = (p.Tp + 127) / 128;
     dim3 grid(q.n_qtiles * 4 * p.B);

@@ -2,8 +2,7 @@
 //
 // Per layer (d = 512):   h = LN1(x)                      ln kernel            bf16 [M][K]
 //                         qkv = h Wqkv^T + b              MFMA GEMM            bf16 [M][1536]
-//                         fsmn, V^T = FSMN(v), mask       fsmn kernel          16-bit [M][512], 16-bit [B][512][Tk]
-//                         att = softmax(q k^T / sqrt(128)) v   attention kernel bf16 [M][512]
+//                         att = softmax(q k^T / sqrt(128)) v,  fsmn = FSMN(v)   attention kernel   16-bit [M][512] each
 //                         x = att Wo^T + b + fsmn (+ x)   MFMA GEMM            f32 [M][512]   (layer 0 has no residual)
 //                         h = LN2(x)                      ln kernel
 //                         f = relu(h W1^T + b)            MFMA GEMM            bf16 [M][2048]
@@ -33,7 +32,6 @@ struct Buffers {
     float* x;        // [M][512]
     uint16_t* h;     // [M][max(kin_pad, 512)]
     uint16_t* qkv;   // [M][1536]
-    uint16_t* vt;    // [B][512][Tk]
     uint16_t* fsmn;  // [M][512]
     uint16_t* att;   // [M][512]
     uint16_t* ffn;   // [M][ff]
@@ -43,14 +41,12 @@ struct Buffers {
 
 Buffers carve(const asrfe_ctx* ctx, void* ws, int B, int Tp) {
     const int64_t M = static_cast<int64_t>(B) * Tp;
-    const int64_t Tk = (Tp + 63) / 64 * 64;
     const int64_t hk = ctx->kin_pad > 512 ? ctx->kin_pad : 512;
     Carve c{static_cast<char*>(ws)};
     Buffers b;
     b.x = c.take<float>(M * 512);
     b.h = c.take<uint16_t>(M * hk);
     b.qkv = c.take<uint16_t>(M * 1536);
-    b.vt = c.take<uint16_t>(static_cast<int64_t>(B) * 512 * Tk);
     b.fsmn = c.take<uint16_t>(M * 512);
     b.att = c.take<uint16_t>(M * 512);
     b.ffn = c.take<uint16_t>(M * ctx->cfg.enc_linear_units);
@@ -69,7 +65,6 @@ int32_t encoder_forward(asrfe_ctx* ctx, const float* feats, const int32_t* lens,
     (void)ws_bytes;
     const asrfe_config& c = ctx->cfg;
     const int M = B * Tp;
-    const int Tk = (Tp + 63) / 64 * 64;
     const int ff = c.enc_linear_units;
     const Buffers bf = carve(ctx, ws, B, Tp);
     int32_t rc;
@@ -100,12 +95,10 @@ int32_t encoder_forward(asrfe_ctx* ctx, const float* feats, const int32_t* lens,
         { ProfScope ps(ctx, PK_GEMM_QKV, s); rc = launch_gemm(ctx, g, EPI_BF16, s); }
         if (rc) return rc;
 
-        { ProfScope ps(ctx, PK_FSMN, s); rc = launch_fsmn(ctx, bf.qkv, 1536, L.w_fsmn, lens, B, Tp, Tk, bf.fsmn, bf.vt, s); }
-        if (rc) return rc;
-
         AttnParams a{};
-        a.qkv = bf.qkv; a.ld_qkv = 1536; a.vt = bf.vt; a.lens = lens; a.out = bf.att; a.ld_out = 512;
-        a.B = B; a.Tp = Tp; a.Tk = Tk;
+        a.qkv = bf.qkv; a.ld_qkv = 1536; a.lens = lens; a.out = bf.att; a.ld_out = 512;
+        a.fsmn = bf.fsmn; a.w_fsmn = L.w_fsmn;
+        a.B = B; a.Tp = Tp;
         a.scale_log2 = 1.4426950408889634f / std::sqrt(128.0f);
         { ProfScope ps(ctx, PK_ATTN, s); rc = launch_attention(ctx, a, s); }
         if (rc) return rc;

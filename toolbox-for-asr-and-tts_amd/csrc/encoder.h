@@ -6,13 +6,14 @@
 namespace asrfe {
 
 struct AttnParams {
-    const uint16_t* qkv;  // bf16 [B*Tp][ld_qkv]: q at column head*128, k at 512 + head*128
+    const uint16_t* qkv;  // 16-bit [B*Tp][ld_qkv]: q at column head*128, k at 512 + head*128, v at 1024 + head*128
     int ld_qkv;
-    const uint16_t* vt;   // bf16 [B][512][Tk], zero at t >= lens[b]
     const int32_t* lens;  // [B]
-    uint16_t* out;        // bf16 [B*Tp][ld_out]
+    uint16_t* out;        // 16-bit [B*Tp][ld_out] attention output
     int ld_out;
-    int B, Tp, Tk;
+    uint16_t* fsmn;       // 16-bit [B*Tp][512] FSMN memory block of v (rows t >= lens[b] zero)
+    const float* w_fsmn;  // f32 [11][512] taps, tap-major
+    int B, Tp;
     int n_qtiles;         // filled by launch_attention
     float scale_log2;     // log2(e) / sqrt(d_k)
 };
@@ -54,9 +55,5 @@ struct FfnParams {
     int flags;             // timing experiments only (results are wrong): bit 0 skips the stores
 };
 int32_t launch_post_attn(asrfe_ctx* ctx, const FfnParams& p, hipStream_t s);
-
-// FSMN memory block on V (columns 1024..1535 of qkv) and the transposed V copy for attention
-int32_t launch_fsmn(asrfe_ctx* ctx, const uint16_t* qkv, int ld_qkv, const float* w /*[11][512]*/, const int32_t* lens,
-                    int B, int Tp, int Tk, uint16_t* fsmn /*[B*Tp][512]*/, uint16_t* vt /*[B][512][Tk]*/, hipStream_t s);
 
 }  // namespace asrfe

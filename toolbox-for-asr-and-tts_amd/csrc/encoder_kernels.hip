@@ -1,6 +1,5 @@
-// Memory-bound kernels of the SAN-M encoder on gfx950: sinusoidal position table, the LayerNorm
-// variants (one wave per row, fp32 statistics, 16-byte loads) and the FSMN memory block, which also
-// emits the transposed, length-masked copy of V that the attention kernel consumes.
+// Memory-bound kernels of the SAN-M encoder on gfx950: sinusoidal position table and the LayerNorm
+// variants (one wave per row, fp32 statistics, 16-byte loads).
 #include "common.h"
 #include "elem.h"
 #include "encoder.h"
@@ -147,96 +146,6 @@ int32_t launch_ln_final(asrfe_ctx* ctx, const float* x, const float* g, const fl
     if (out_dtype == ASRFE_DT_BF16) return launch_ln<2, 3>(ctx, p, false, s, "ln_final");
     if (out_dtype == ASRFE_DT_F16) return launch_ln<2, 3>(ctx, p, true, s, "ln_final");
     return launch_ln<2, 2>(ctx, p, false, s, "ln_final");
-}
-
-// ---- FSMN memory block ----------------------------------------------------------------------------
-// fsmn[t][d] = mask_t * (sum_j w[j][d] * vm[t + j - 5][d] + vm[t][d]),  vm = v inside the utterance, else 0.
-// One workgroup handles 64 time steps x 64 channels of one utterance: the 74 x 64 input tile (5 halo rows
-// each side) is staged once in LDS as floats; a thread keeps the 11 taps of its 4 channels in registers and
-// walks 4 rows, so 16 lanes write one full 128-byte line of the 16-bit output; the same tile is then read
-// column-wise to emit the transposed, masked copy of V.
-constexpr int kFsmnTaps = 11;
-constexpr int kFsmnHalo = 5;
-constexpr int kFsmnRows = 64 + 2 * kFsmnHalo;  // 74
-constexpr int kFsmnLd = 68;                    // floats per tile row (16-byte aligned rows)
-
-template <bool F16>
-__global__ __launch_bounds__(256) void fsmn_kernel(const uint16_t* __restrict__ qkv, int ld_qkv,
-                                                   const float* __restrict__ w, const int32_t* __restrict__ lens,
-                                                   int Tp, int Tk, uint16_t* __restrict__ fsmn,
-                                                   uint16_t* __restrict__ vt) {
-    __shared__ __attribute__((aligned(16))) float tile[kFsmnRows * kFsmnLd];
-    const int tid = threadIdx.x;
-    const int t0 = blockIdx.x * 64, d0 = blockIdx.y * 64, b = blockIdx.z;
-    int len = lens[b];
-    len = len < 0 ? 0 : (len > Tp ? Tp : len);
-    const int64_t row0 = static_cast<int64_t>(b) * Tp;
-
-    // rows t0-5 .. t0+68, 8 channels (16 bytes) per load
-    for (int c = tid; c < kFsmnRows * 8; c += 256) {
-        const int r = c >> 3, ch = (c & 7) * 8;
-        const int t = t0 - kFsmnHalo + r;
-        uint4 raw = make_uint4(0, 0, 0, 0);
-        if (t >= 0 && t < len)
-            raw = *reinterpret_cast<const uint4*>(qkv + (row0 + t) * ld_qkv + 1024 + d0 + ch);
-        float f[8];
-        unpack_elem2<F16>(raw.x, f[0], f[1]);
-        unpack_elem2<F16>(raw.y, f[2], f[3]);
-        unpack_elem2<F16>(raw.z, f[4], f[5]);
-        unpack_elem2<F16>(raw.w, f[6], f[7]);
-        *reinterpret_cast<float4*>(&tile[r * kFsmnLd + ch]) = make_float4(f[0], f[1], f[2], f[3]);
-        *reinterpret_cast<float4*>(&tile[r * kFsmnLd + ch + 4]) = make_float4(f[4], f[5], f[6], f[7]);
-    }
-    // taps of this thread's 4 channels
-    const int dq = (tid & 15) * 4;
-    float4 wt[kFsmnTaps];
-#pragma unroll
-    for (int j = 0; j < kFsmnTaps; ++j) wt[j] = *reinterpret_cast<const float4*>(w + j * 512 + d0 + dq);
-    __syncthreads();
-
-#pragma unroll 1
-    for (int pass = 0; pass < 4; ++pass) {
-        const int tt = pass * 16 + (tid >> 4);
-        const int t = t0 + tt;
-        float4 acc = *reinterpret_cast<const float4*>(&tile[(tt + kFsmnHalo) * kFsmnLd + dq]);
-#pragma unroll
-        for (int j = 0; j < kFsmnTaps; ++j) {
-            const float4 x = *reinterpret_cast<const float4*>(&tile[(tt + j) * kFsmnLd + dq]);
-            acc.x = fmaf(wt[j].x, x.x, acc.x);
-            acc.y = fmaf(wt[j].y, x.y, acc.y);
-            acc.z = fmaf(wt[j].z, x.z, acc.z);
-            acc.w = fmaf(wt[j].w, x.w, acc.w);
-        }
-        if (t < Tp) {
-            const bool live = t < len;
-            *reinterpret_cast<uint2*>(fsmn + (row0 + t) * 512 + d0 + dq) =
-                live ? make_uint2(pack_elem2<F16>(acc.x, acc.y), pack_elem2<F16>(acc.z, acc.w)) : make_uint2(0u, 0u);
-        }
-    }
-    // transposed V: thread = (channel dd, 16 consecutive time steps); masked rows are already zero in the tile
-    {
-        const int dd = tid >> 2, tq = (tid & 3) * 16;
-        uint32_t pk[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e)
-            pk[e] = pack_elem2<F16>(tile[(kFsmnHalo + tq + 2 * e) * kFsmnLd + dd], tile[(kFsmnHalo + tq + 2 * e + 1) * kFsmnLd + dd]);
-        uint4* o = reinterpret_cast<uint4*>(vt + (static_cast<int64_t>(b) * 512 + d0 + dd) * Tk + t0 + tq);
-        o[0] = make_uint4(pk[0], pk[1], pk[2], pk[3]);
-        o[1] = make_uint4(pk[4], pk[5], pk[6], pk[7]);
-    }
-}
-
-int32_t launch_fsmn(asrfe_ctx* ctx, const uint16_t* qkv, int ld_qkv, const float* w, const int32_t* lens, int B, int Tp,
-                    int Tk, uint16_t* fsmn, uint16_t* vt, hipStream_t s) {
-    if (B <= 0 || Tp <= 0) return ASRFE_OK;
-    if (Tk % 64 != 0 || Tk < Tp) return set_err(ctx, ASRFE_ERR_SHAPE, "fsmn: Tk must be Tp rounded up to 64");
-    if (ctx->cfg.enc_compute_dtype == ASRFE_DT_F16)
-        hipLaunchKernelGGL(fsmn_kernel<true>, dim3(Tk / 64, 8, B), dim3(256), 0, s, qkv, ld_qkv, w, lens, Tp, Tk, fsmn, vt);
-    else
-        hipLaunchKernelGGL(fsmn_kernel<false>, dim3(Tk / 64, 8, B), dim3(256), 0, s, qkv, ld_qkv, w, lens, Tp, Tk, fsmn, vt);
-    const hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return set_err(ctx, ASRFE_ERR_HIP, std::string("fsmn launch: ") + hipGetErrorString(e));
-    return ASRFE_OK;
 }
 
 }  // namespace asrfe
