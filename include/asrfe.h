@@ -177,6 +177,13 @@ int32_t asrfe_debug_gemm(asrfe_ctx* ctx, const void* a, int32_t lda, const void*
 int32_t asrfe_debug_post_attn(asrfe_ctx* ctx, int32_t layer, const void* att, const void* fsmn, const float* x,
                               float* x_out, void* y, int32_t m, int32_t flags, void* stream);
 
+/* Kernel-level test hook (no counterpart in the reference): one launch of the attention + FSMN kernel of encoder
+ * layer `layer` on qkv [batch * tp][1536] (16-bit compute dtype; q | k | v, 4 heads of 128) with lens [batch]:
+ * att [batch * tp][512] = softmax(q k^T / sqrt(128), keys < lens[b]) v per head, and fsmn [batch * tp][512] = the FSMN
+ * memory block of v (11 taps, rows >= lens[b] zero).  flags != 0 are timing experiments that produce wrong results. */
+int32_t asrfe_debug_attention(asrfe_ctx* ctx, int32_t layer, const void* qkv, const int32_t* lens, int32_t batch,
+                              int32_t tp, void* att, void* fsmn, int32_t flags, void* stream);
+
 /* Text of the last error on this context (or of the last failed asrfe_create when ctx is NULL). */
 const char* asrfe_last_error(const asrfe_ctx* ctx);
 const char* asrfe_version(void);

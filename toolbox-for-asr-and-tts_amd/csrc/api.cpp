@@ -598,6 +598,21 @@ extern "C" int32_t asrfe_debug_post_attn(asrfe_ctx* ctx, int32_t layer, const vo
     return launch_post_attn(ctx, f, static_cast<hipStream_t>(stream));
 }
 
+extern "C" int32_t asrfe_debug_attention(asrfe_ctx* ctx, int32_t layer, const void* qkv, const int32_t* lens, int32_t batch,
+                                         int32_t tp, void* att, void* fsmn, int32_t flags, void* stream) {
+    if (!ctx || !qkv || !lens || !att || !fsmn) return set_err(ctx, ASRFE_ERR_BAD_ARG, "asrfe_debug_attention: null argument");
+    if (!ctx->enc_loaded) return set_err(ctx, ASRFE_ERR_NOT_LOADED, "asrfe_debug_attention: encoder weights not loaded");
+    if (layer < 0 || layer >= ctx->cfg.enc_num_blocks) return set_err(ctx, ASRFE_ERR_BAD_ARG, "asrfe_debug_attention: no such layer");
+    AttnParams a{};
+    a.qkv = static_cast<const uint16_t*>(qkv); a.ld_qkv = 1536; a.lens = lens;
+    a.out = static_cast<uint16_t*>(att); a.ld_out = 512;
+    a.fsmn = static_cast<uint16_t*>(fsmn); a.w_fsmn = ctx->layers[layer].w_fsmn;
+    a.B = batch; a.Tp = tp;
+    a.scale_log2 = 1.4426950408889634f / std::sqrt(128.0f);
+    a.flags = flags;
+    return launch_attention(ctx, a, static_cast<hipStream_t>(stream));
+}
+
 // ---- encoder entry points ----------------------------------------------------------------------
 extern "C" int64_t asrfe_encoder_workspace_bytes(const asrfe_ctx* ctx, int32_t batch, int32_t tp) {
     if (!ctx || batch < 0 || tp < 0) return -1;

@@ -31,15 +31,15 @@ constexpr int kTileBytes = 64 * 256;       // 64 keys x 128 d, 16-bit
 constexpr int kBufBytes = 2 * kTileBytes;  // K tile | V tile
 constexpr int kFsmnHalo = 5;
 constexpr int kFsmnTaps = 11;
-static_assert(kTileBytes + 9 * 4096 <= 2 * kBufBytes, "FSMN stage (9 DMA rounds of 16 rows = 128 + 2 x 5 halo rows, rounded up) fits behind K tile 0");
+constexpr int kFsmnStage = kBufBytes;      // byte offset of the FSMN stage: 9 DMA rounds of 16 rows (128 + 2 x 5 halo, rounded up)
 
 typedef short v4s __attribute__((ext_vector_type(4)));
 
 template <bool F16>
 __global__ __launch_bounds__(kAttnThreads, 2) void attn_kernel(const AttnParams p) {
-    // two K/V buffers: tile kt + 1 is fetched while tile kt is multiplied.  The FSMN phase stages its rows in
-    // bytes [16 KiB, 52 KiB) while K tile 0 already flies into [0, 16 KiB).
-    __shared__ __attribute__((aligned(16))) char smem[2 * kBufBytes];
+    // two K/V buffers: tile kt + 1 is fetched while tile kt is multiplied.  The FSMN phase stages its 144 rows in
+    // bytes [32 KiB, 68 KiB), i.e. over buffer 1 plus 4 KiB, so that K and V tile 0 fly into buffer 0 at the same time.
+    __shared__ __attribute__((aligned(16))) char smem[2 * kBufBytes + 4096];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -79,22 +79,23 @@ __global__ __launch_bounds__(kAttnThreads, 2) void attn_kernel(const AttnParams 
             if (with_v) lds_dma16(vbase, ro + v_chunk * 16, dst + kTileBytes + i * 4096);
         }
     };
-    auto v_issue = [&](int kt, int buf) {
-        const uint32_t dst = __builtin_amdgcn_readfirstlane(smem_base + buf * kBufBytes + kTileBytes + wave * 1024);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            int key = kt * 64 + i * 16 + st_row;
-            key = key < p.Tp ? key : p.Tp - 1;
-            lds_dma16(vbase, static_cast<uint32_t>(key) * ldb + v_chunk * 16, dst + i * 4096);
-        }
-    };
+    if (n_kt > 0) kv_issue(0, 0, true);
 
-    if (n_kt > 0) kv_issue(0, 0, false);  // K tile 0; V tile 0 follows the FSMN phase (its buffer is the FSMN stage)
+    // Q fragments: lane holds Q[q0 + l31][16 s + 8 h .. +8), s = 0..7
+    u16x8 qf[8];
+    {
+        int qr = q0 + l31;
+        qr = qr < p.Tp ? qr : p.Tp - 1;
+        const uint16_t* qp = p.qkv + (row0 + qr) * p.ld_qkv + head * 128 + 8 * h;
+#pragma unroll
+        for (int s = 0; s < 8; ++s) qf[s] = *reinterpret_cast<const u16x8*>(qp + 16 * s);
+    }
 
     // ---- FSMN memory block for rows qb .. qb + 127 of this head -----------------------------------------------
-    {
+    const int xf = p.flags;  // timing experiments
+    if (!(xf & 1)) {
         // stage row rr (0..143) = V row qb - 5 + rr, clamped into the utterance's rows (masked when used)
-        const uint32_t fst = __builtin_amdgcn_readfirstlane(smem_base + kTileBytes + wave * 1024);
+        const uint32_t fst = __builtin_amdgcn_readfirstlane(smem_base + kFsmnStage + wave * 1024);
 #pragma unroll
         for (int i = 0; i < 9; ++i) {
             int t = qb - kFsmnHalo + i * 16 + st_row;
@@ -112,55 +113,44 @@ __global__ __launch_bounds__(kAttnThreads, 2) void attn_kernel(const AttnParams 
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        const char* fs = smem + kTileBytes + (32 * rg) * 256 + 4 * cp;
-        float x0[kFsmnTaps], x1[kFsmnTaps];  // window: x[j] = v_m[t + j - 5]
+        const char* fs = smem + kFsmnStage + (32 * rg) * 256 + 4 * cp;
+        // all 42 stage rows of this thread's window walk are read up front (one LDS latency, not 42)
+        uint32_t raw[32 + kFsmnTaps - 1];
 #pragma unroll
-        for (int j = 0; j < kFsmnTaps - 1; ++j) {
-            const int tt = qb + 32 * rg + j - kFsmnHalo;  // time of stage row 32 rg + j
-            const uint32_t raw = *reinterpret_cast<const uint32_t*>(fs + j * 256);
-            unpack_elem2<F16>(raw, x0[j + 1], x1[j + 1]);
-            if (tt < 0 || tt >= len) x0[j + 1] = x1[j + 1] = 0.0f;
-        }
+        for (int r = 0; r < 32 + kFsmnTaps - 1; ++r) raw[r] = *reinterpret_cast<const uint32_t*>(fs + r * 256);
+        // xw[r % 11] holds v_m of stage row r (time qb + 32 rg + r - 5); the loops are fully unrolled, so the
+        // rotating index is a compile-time constant and the window never moves between registers
+        float x0[kFsmnTaps], x1[kFsmnTaps];
+        auto put = [&](int r) {
+            const int tt = qb + 32 * rg + r - kFsmnHalo;
+            float a, bq;
+            unpack_elem2<F16>(raw[r], a, bq);
+            const bool ok = tt >= 0 && tt < len;
+            x0[r % kFsmnTaps] = ok ? a : 0.0f;
+            x1[r % kFsmnTaps] = ok ? bq : 0.0f;
+        };
+#pragma unroll
+        for (int r = 0; r < kFsmnTaps - 1; ++r) put(r);
         uint32_t* out = reinterpret_cast<uint32_t*>(p.fsmn + (row0 + qb + 32 * rg) * 512 + head * 128 + 2 * cp);
 #pragma unroll
         for (int i = 0; i < 32; ++i) {
             const int t = qb + 32 * rg + i;
-#pragma unroll
-            for (int j = 0; j < kFsmnTaps - 1; ++j) {
-                x0[j] = x0[j + 1];
-                x1[j] = x1[j + 1];
-            }
-            {
-                const int tt = t + kFsmnHalo;
-                const uint32_t raw = *reinterpret_cast<const uint32_t*>(fs + (i + kFsmnTaps - 1) * 256);
-                unpack_elem2<F16>(raw, x0[kFsmnTaps - 1], x1[kFsmnTaps - 1]);
-                if (tt >= len) x0[kFsmnTaps - 1] = x1[kFsmnTaps - 1] = 0.0f;
-            }
-            float a0 = x0[kFsmnHalo], a1 = x1[kFsmnHalo];
+            put(i + kFsmnTaps - 1);
+            float a0 = x0[(i + kFsmnHalo) % kFsmnTaps], a1 = x1[(i + kFsmnHalo) % kFsmnTaps];
 #pragma unroll
             for (int j = 0; j < kFsmnTaps; ++j) {
-                a0 = fmaf(w0[j], x0[j], a0);
-                a1 = fmaf(w1[j], x1[j], a1);
+                a0 = fmaf(w0[j], x0[(i + j) % kFsmnTaps], a0);
+                a1 = fmaf(w1[j], x1[(i + j) % kFsmnTaps], a1);
             }
             if (t < p.Tp) out[static_cast<int64_t>(i) * 256] = t < len ? pack_elem2<F16>(a0, a1) : 0u;
         }
-        __syncthreads();  // the stage is consumed: its bytes become V tile 0 / K, V tile 1
+        __syncthreads();  // the stage is consumed: its bytes become K, V tile 1
     }
-    if (n_kt > 0) v_issue(0, 0);
 
-    // Q fragments: lane holds Q[q0 + l31][16 s + 8 h .. +8), s = 0..7
-    u16x8 qf[8];
-    {
-        int qr = q0 + l31;
-        qr = qr < p.Tp ? qr : p.Tp - 1;
-        const uint16_t* qp = p.qkv + (row0 + qr) * p.ld_qkv + head * 128 + 8 * h;
+    // Use the Q fragments once here: the compiler then waits for their loads before the loop.  Left to their first
+    // use inside the loop, its vmcnt waits there would also drain the K / V prefetch it does not know about.
 #pragma unroll
-        for (int s = 0; s < 8; ++s) qf[s] = *reinterpret_cast<const u16x8*>(qp + 16 * s);
-        // Use the fragments once here: the compiler then waits for these loads before the loop.  Left to their first
-        // use inside the loop, its vmcnt waits there would also drain the K / V prefetch it does not know about.
-#pragma unroll
-        for (int s = 0; s < 8; ++s) asm volatile("" : "+v"(qf[s]));
-    }
+    for (int s = 0; s < 8; ++s) asm volatile("" : "+v"(qf[s]));
 
     // transposed V reads: lane 4 q + pp of a 16-lane group addresses key row q of the 4-key block, channels
     // 4 pp .. 4 pp + 3 of the group's 16; groups 0, 1 (h = 0) and 2, 3 (h = 1) take keys 4 h .. 4 h + 3 of each 8.
@@ -192,8 +182,8 @@ __global__ __launch_bounds__(kAttnThreads, 2) void attn_kernel(const AttnParams 
         // kt - 1, whose buffer is refilled below
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        if (kt + 1 < n_kt) kv_issue(kt + 1, cur ^ 1, true);
-        const char* ks = smem + cur * kBufBytes;
+        if (kt + 1 < n_kt && !(xf & 8)) kv_issue(kt + 1, cur ^ 1, true);
+        const char* ks = smem + ((xf & 8) ? 0 : cur) * kBufBytes;
         const char* vs = ks + kTileBytes;
 
         // ---- S^T = K Q^T : two 32-key sub-tiles ---------------------------------------------
@@ -203,10 +193,12 @@ __global__ __launch_bounds__(kAttnThreads, 2) void attn_kernel(const AttnParams 
 #pragma unroll
             for (int e = 0; e < 16; ++e) sacc[kk][e] = 0.0f;
             const char* krow = ks + (kk * 32 + l31) * 256;
+            if (!(xf & 4)) {
 #pragma unroll
             for (int s = 0; s < 8; ++s) {
                 const u16x8 kf = *reinterpret_cast<const u16x8*>(krow + (((2 * s + h) ^ (l31 & 15)) << 4));
                 sacc[kk] = mfma32<F16>(kf, qf[s], sacc[kk]);
+            }
             }
         }
         if (kt == n_kt - 1) {  // wave-uniform: mask keys at or past the utterance length
@@ -224,48 +216,51 @@ __global__ __launch_bounds__(kAttnThreads, 2) void attn_kernel(const AttnParams 
 #pragma unroll
             for (int e = 0; e < 16; ++e) rmax = fmaxf(rmax, sacc[kk][e]);
         rmax = fmaxf(rmax, __shfl_xor(rmax, 32));
-        const float m_new = fmaxf(m_run, rmax);  // finite: every tile holds at least one valid key
-        const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);
+        // The running maximum only has to bound the scores well enough for exp2 to stay in range: it is raised
+        // (and the accumulators rescaled) only when the tile's maximum exceeds it by more than 2^8 after scaling,
+        // so most tiles skip the rescale.  Every tile holds at least one valid key, so rmax is finite.
+        const bool grew = rmax * c > m_run * c + 8.0f;  // true on the first tile (m_run = -inf)
+        const float m_new = grew ? rmax : m_run;
+        const float alpha = grew ? __builtin_amdgcn_exp2f((m_run - m_new) * c) : 1.0f;
         const float mc = m_new * c;
-        const bool grew = m_new != m_run;
         m_run = m_new;
-        float psum = 0.0f;
-        u16x8 pf[2][2];
+        if (__any(grew)) {  // no lane raised its maximum: alpha is exactly 1 everywhere, skip the rescale
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk)
+            for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) oacc[mt][e] *= alpha;
+        }
+        // ---- P = exp2(...) and O^T += V^T P^T, one 32-key sub-tile at a time: the MFMAs of sub-tile 0 have the
+        //      exponentials of sub-tile 1 to overlap with (one straight-line block for the scheduler)
+        float psum = 0.0f;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            u16x8 pf[2];
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     const float pv = __builtin_amdgcn_exp2f(sacc[kk][8 * s2 + j] * c - mc);
                     psum += pv;
-                    pf[kk][s2][j] = to_elem<F16>(pv);
+                    pf[s2][j] = to_elem<F16>(pv);
                 }
+            if (!(xf & 2)) {
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                    for (int s2 = 0; s2 < 2; ++s2) {
+                        // element j of the fragment is key 32 kk + 16 s2 + 8 (j >> 2) + 4 h + (j & 3)
+                        const char* blk = vs + (kk * 32 + s2 * 16) * 256;
+                        const v4s lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                            (__attribute__((address_space(3))) v4s*)(blk + vtr[mt][0]));
+                        const v4s hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                            (__attribute__((address_space(3))) v4s*)(blk + vtr[mt][1]));
+                        const u16x8 vf = __builtin_bit_cast(u16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+                        oacc[mt] = mfma32<F16>(vf, pf[s2], oacc[mt]);
+                    }
+            }
+        }
         l_run = l_run * alpha + psum;
-        if (__any(grew)) {  // no lane's maximum moved: alpha is exactly 1 everywhere, skip the rescale
-#pragma unroll
-            for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-                for (int e = 0; e < 16; ++e) oacc[mt][e] *= alpha;
-        }
-
-        // ---- O^T += V^T P^T ----------------------------------------------------------------------
-#pragma unroll
-        for (int mt = 0; mt < 4; ++mt) {
-#pragma unroll
-            for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-                for (int s2 = 0; s2 < 2; ++s2) {
-                    // element j of the fragment is key 32 kk + 16 s2 + 8 (j >> 2) + 4 h + (j & 3)
-                    const char* blk = vs + (kk * 32 + s2 * 16) * 256;
-                    const v4s lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                        (__attribute__((address_space(3))) v4s*)(blk + vtr[mt][0]));
-                    const v4s hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                        (__attribute__((address_space(3))) v4s*)(blk + vtr[mt][1]));
-                    const u16x8 vf = __builtin_bit_cast(u16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
-                    oacc[mt] = mfma32<F16>(vf, pf[kk][s2], oacc[mt]);
-                }
-        }
     }
 
     // ---- normalise; each wave routes its 32 x 128 tile through LDS so that 16 lanes store one full 256-byte row ----

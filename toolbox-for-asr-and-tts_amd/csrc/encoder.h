@@ -16,6 +16,7 @@ struct AttnParams {
     int B, Tp;
     int n_qtiles;         // filled by launch_attention
     float scale_log2;     // log2(e) / sqrt(d_k)
+    int flags;            // timing experiments only (results are wrong when set)
 };
 int32_t launch_attention(asrfe_ctx* ctx, const AttnParams& p, hipStream_t s);
 

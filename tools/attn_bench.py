@@ -1,0 +1,95 @@
+#!/usr/bin/env python3
+"""Times and checks the attention + FSMN kernel in isolation (through asrfe_debug_attention).
+
+    python tools/attn_bench.py [--check] [--iters 30] [--flags 0 1 ...]
+"""
+import argparse
+import ctypes as C
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import toolbox_for_asr_and_tts_amd as pkg  # noqa: E402
+from toolbox_for_asr_and_tts_amd.synth import encoder_state_dict  # noqa: E402
+
+
+def reference(qkv, lens, w):
+    """fp64 attention and FSMN on the 16-bit-rounded inputs. qkv [B, T, 1536], w [512, 1, 11]."""
+    B, T, _ = qkv.shape
+    q, k, v = [t.double() for t in qkv.split(512, dim=-1)]
+    mask = (torch.arange(T, device=qkv.device)[None, :] < lens[:, None])
+    att = torch.zeros(B, T, 512, dtype=torch.float64, device=qkv.device)
+    for hd in range(4):
+        sl = slice(128 * hd, 128 * hd + 128)
+        s = q[..., sl] @ k[..., sl].transpose(1, 2) / 128 ** 0.5
+        s = s.masked_fill(~mask[:, None, :], float("-inf"))
+        att[..., sl] = torch.softmax(s, dim=-1) @ v[..., sl]
+    vm = v * mask[..., None]
+    x = torch.nn.functional.pad(vm.transpose(1, 2), (5, 5))
+    f = torch.nn.functional.conv1d(x, w.double(), groups=512).transpose(1, 2) + vm
+    return att, f * mask[..., None]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--check", action="store_true")
+    ap.add_argument("--iters", type=int, default=30)
+    ap.add_argument("--repeat", type=int, default=2)
+    ap.add_argument("--flags", type=int, nargs="*", default=[0])
+    args = ap.parse_args()
+    enc = pkg.SANMEncoder(num_blocks=1)
+    sd = encoder_state_dict(num_blocks=1, seed=3)
+    sd["encoders0.0.self_attn.fsmn_block.weight"] = torch.randn(512, 1, 11) * 0.2
+    enc.load_state_dict(sd)
+    ctx, lib = enc.ctx, enc.ctx.lib
+    dev = "cuda"
+    stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    w = sd["encoders0.0.self_attn.fsmn_block.weight"].to(dev)
+
+    def launch(qkv, lens, att, fsmn, flags=0):
+        B, T, _ = qkv.shape
+        ctx.check(lib.asrfe_debug_attention(ctx.handle, 0, qkv.data_ptr(), lens.data_ptr(), B, T, att.data_ptr(),
+                                            fsmn.data_ptr(), flags, stream))
+
+    if args.check:
+        for T, ll in [(1, [1]), (7, [7, 3]), (64, [64, 5]), (130, [130, 77, 128]), (500, [500, 333, 64, 6])]:
+            B = len(ll)
+            qkv = (torch.randn(B, T, 1536, device=dev) * 1.5).half()
+            lens = torch.tensor(ll, dtype=torch.int32, device=dev)
+            att = torch.empty(B, T, 512, device=dev, dtype=torch.float16)
+            fsmn = torch.empty(B, T, 512, device=dev, dtype=torch.float16)
+            launch(qkv, lens, att, fsmn)
+            ra, rf = reference(qkv, lens, w)
+            valid = (torch.arange(T, device=dev)[None, :] < lens[:, None])[..., None]
+            e1 = ((att.double() - ra) * valid).abs().max().item()
+            e2 = (fsmn.double() - rf).abs().max().item()
+            print(f"check T={T} lens={ll}: att err {e1:.3e}, fsmn err {e2:.3e}")
+            assert e1 < 4e-3 and e2 < 8e-3
+    B, T = 64, 500
+    qkv = (torch.randn(B, T, 1536, device=dev) * 1.5).half()
+    lens = torch.full((B,), T, dtype=torch.int32, device=dev)
+    att = torch.empty(B, T, 512, device=dev, dtype=torch.float16)
+    fsmn = torch.empty(B, T, 512, device=dev, dtype=torch.float16)
+    t0 = time.time()
+    while time.time() - t0 < 1.0:
+        for _ in range(50):
+            launch(qkv, lens, att, fsmn)
+        torch.cuda.synchronize()
+    for flags in args.flags * args.repeat:
+        for _ in range(5):
+            launch(qkv, lens, att, fsmn, flags)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(args.iters):
+            launch(qkv, lens, att, fsmn, flags)
+        e1.record()
+        torch.cuda.synchronize()
+        us = 1e3 * e0.elapsed_time(e1) / args.iters
+        print(f"attention+fsmn B={B} T={T} flags={flags}: {us:7.1f} us  {4 * B * 4 * T * T * 128 / us / 1e6:7.1f} TFLOP/s")
+
+
+if __name__ == "__main__":
+    main()
