@@ -90,6 +90,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-stages", action="store_true")
     ap.add_argument("--streams", type=int, default=2, help="HIP streams (batch chunks) per GPU")
+    ap.add_argument("--graph", type=int, default=0, help="1: replay the step from a captured HIP graph")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -120,12 +121,20 @@ def main():
         if dist is not None:
             dist.barrier()
 
-    for _ in range(args.warmup):
+    step = lambda: eng.run(pcm, lens)
+    if args.graph:
         eng.run(pcm, lens)
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            eng.run(pcm, lens)
+        step = graph.replay
+    for _ in range(args.warmup):
+        step()
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        eng.run(pcm, lens)
+        step()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     if dist is not None:

@@ -404,3 +404,62 @@ def test_engine_streams_give_identical_results(pkg):
     out0 = e1.run(dev(clips), lens)[0]
     torch.cuda.synchronize()
     assert torch.equal(out0, out2)
+
+
+def test_attention_fsmn_kernel_vs_fp64(pkg):
+    """The attention + FSMN kernel on its own (debug hook) against an fp64 evaluation of the same 16-bit inputs:
+    ragged lengths, a length below the FSMN half-width, T' around the 64-key and 128-query tile edges."""
+    import ctypes as C
+    cfg = so.SanmConfig(num_blocks=1)
+    sd = so.make_state_dict(cfg, seed=2, dtype=torch.float32)
+    gen = torch.Generator().manual_seed(3)
+    sd["encoders0.0.self_attn.fsmn_block.weight"] = torch.randn(512, 1, 11, generator=gen) * 0.2
+    enc = pkg.SANMEncoder(num_blocks=1)
+    enc.load_state_dict(sd)
+    ctx = enc.ctx
+    stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    w = sd["encoders0.0.self_attn.fsmn_block.weight"].double().cuda()
+    for T, ll in [(1, [1]), (7, [7, 3]), (64, [64, 5]), (65, [65, 64, 2]), (129, [129, 128, 127]), (300, [300, 191, 64, 6])]:
+        B = len(ll)
+        qkv = (torch.randn(B, T, 1536, generator=gen) * 1.5).half().cuda()
+        lens = torch.tensor(ll, dtype=torch.int32, device="cuda")
+        att = torch.full((B, T, 512), float("nan"), dtype=torch.float16, device="cuda")
+        fsmn = torch.full((B, T, 512), float("nan"), dtype=torch.float16, device="cuda")
+        ctx.check(ctx.lib.asrfe_debug_attention(ctx.handle, 0, qkv.data_ptr(), lens.data_ptr(), B, T, att.data_ptr(),
+                                                fsmn.data_ptr(), 0, stream))
+        q, k, v = [t.double() for t in qkv.split(512, dim=-1)]
+        mask = torch.arange(T, device="cuda")[None, :] < lens[:, None]
+        ref = torch.zeros(B, T, 512, dtype=torch.float64, device="cuda")
+        for hd in range(4):
+            sl = slice(128 * hd, 128 * hd + 128)
+            s = (q[..., sl] @ k[..., sl].transpose(1, 2) / math.sqrt(128.0)).masked_fill(~mask[:, None, :], float("-inf"))
+            ref[..., sl] = torch.softmax(s, dim=-1) @ v[..., sl]
+        vm = v * mask[..., None]
+        fref = (torch.nn.functional.conv1d(torch.nn.functional.pad(vm.transpose(1, 2), (5, 5)), w, groups=512).transpose(1, 2)
+                + vm) * mask[..., None]
+        assert torch.isfinite(att.float()).all() and torch.isfinite(fsmn.float()).all()  # padded rows too: they feed later layers
+        assert float(((att.double() - ref) * mask[..., None]).abs().max()) <= 4e-3, (T, ll)
+        assert float((fsmn.double() - fref).abs().max()) <= 8e-3, (T, ll)
+        assert float((fsmn.float() * (~mask[..., None])).abs().max()) == 0.0
+
+
+def test_engine_step_replays_from_a_hip_graph(pkg):
+    """The compute calls only enqueue kernels on the caller's stream (no allocation, no synchronisation), so a
+    step can be captured into a HIP graph and replayed; the replay reproduces the eager result bit for bit."""
+    n = 16000 * 3
+    clips = np.stack([fo.synth_pcm(k, n, 90 + i) for i, k in enumerate(["gauss", "chirp", "bursts"])])
+    lens = dev(np.array([48000, 30000, 20000], np.int32))
+    sd = so.make_state_dict(so.SanmConfig(num_blocks=2), seed=4)
+    cfg = pkg.default_config()
+    cfg.enc_num_blocks = 2
+    eng = pkg.AsrEngine(batch=3, max_samples=n, cfg=cfg, state_dict=sd, n_streams=2)
+    pcm = dev(clips)
+    want = eng.run(pcm, lens)[0].clone()
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        eng.run(pcm, lens)
+    eng.out.zero_()
+    g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(eng.out, want)
