@@ -34,6 +34,7 @@ constexpr int kFsmnTaps = 11;
 constexpr int kFsmnStage = kBufBytes;      // byte offset of the FSMN stage: 9 DMA rounds of 16 rows (128 + 2 x 5 halo, rounded up)
 
 typedef short v4s __attribute__((ext_vector_type(4)));
+typedef float v2f __attribute__((ext_vector_type(2)));
 
 template <bool F16>
 __global__ __launch_bounds__(kAttnThreads, 2) void attn_kernel(const AttnParams p) {
@@ -103,13 +104,12 @@ __global__ __launch_bounds__(kAttnThreads, 2) void attn_kernel(const AttnParams 
             lds_dma16(vbase, static_cast<uint32_t>(t) * ldb + (tid & 15) * 16, fst + i * 4096);
         }
         // taps of this thread's two channels
-        const int cp = tid & 63, rg = tid >> 6;  // channel pair, group of 32 rows
-        float w0[kFsmnTaps], w1[kFsmnTaps];
+        const int cp = lane, rg = wave;  // channel pair, group of 32 rows (wave-uniform: the time masks are scalar)
+        v2f wt[kFsmnTaps];
 #pragma unroll
         for (int j = 0; j < kFsmnTaps; ++j) {
             const float2 w = *reinterpret_cast<const float2*>(p.w_fsmn + j * 512 + head * 128 + 2 * cp);
-            w0[j] = w.x;
-            w1[j] = w.y;
+            wt[j] = v2f{w.x, w.y};
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
@@ -120,14 +120,14 @@ __global__ __launch_bounds__(kAttnThreads, 2) void attn_kernel(const AttnParams 
         for (int r = 0; r < 32 + kFsmnTaps - 1; ++r) raw[r] = *reinterpret_cast<const uint32_t*>(fs + r * 256);
         // xw[r % 11] holds v_m of stage row r (time qb + 32 rg + r - 5); the loops are fully unrolled, so the
         // rotating index is a compile-time constant and the window never moves between registers
-        float x0[kFsmnTaps], x1[kFsmnTaps];
+        // (both channels of the pair travel as one 2-vector: packed fp32 FMAs)
+        v2f xw[kFsmnTaps];
         auto put = [&](int r) {
             const int tt = qb + 32 * rg + r - kFsmnHalo;
             float a, bq;
             unpack_elem2<F16>(raw[r], a, bq);
-            const bool ok = tt >= 0 && tt < len;
-            x0[r % kFsmnTaps] = ok ? a : 0.0f;
-            x1[r % kFsmnTaps] = ok ? bq : 0.0f;
+            const float ok = (tt >= 0 && tt < len) ? 1.0f : 0.0f;
+            xw[r % kFsmnTaps] = v2f{a, bq} * ok;
         };
 #pragma unroll
         for (int r = 0; r < kFsmnTaps - 1; ++r) put(r);
@@ -136,13 +136,10 @@ __global__ __launch_bounds__(kAttnThreads, 2) void attn_kernel(const AttnParams 
         for (int i = 0; i < 32; ++i) {
             const int t = qb + 32 * rg + i;
             put(i + kFsmnTaps - 1);
-            float a0 = x0[(i + kFsmnHalo) % kFsmnTaps], a1 = x1[(i + kFsmnHalo) % kFsmnTaps];
+            v2f acc = xw[(i + kFsmnHalo) % kFsmnTaps];
 #pragma unroll
-            for (int j = 0; j < kFsmnTaps; ++j) {
-                a0 = fmaf(w0[j], x0[(i + j) % kFsmnTaps], a0);
-                a1 = fmaf(w1[j], x1[(i + j) % kFsmnTaps], a1);
-            }
-            if (t < p.Tp) out[static_cast<int64_t>(i) * 256] = t < len ? pack_elem2<F16>(a0, a1) : 0u;
+            for (int j = 0; j < kFsmnTaps; ++j) acc = __builtin_elementwise_fma(wt[j], xw[(i + j) % kFsmnTaps], acc);
+            if (t < p.Tp) out[static_cast<int64_t>(i) * 256] = t < len ? pack_elem2<F16>(acc.x, acc.y) : 0u;
         }
         __syncthreads();  // the stage is consumed: its bytes become K, V tile 1
     }
