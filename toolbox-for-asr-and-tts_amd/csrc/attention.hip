@@ -93,7 +93,13 @@ __global__ __launch_bounds__(kAttnThreads, 2) void attn_kernel(const AttnParams 
     }
 
     // ---- FSMN memory block for rows qb .. qb + 127 of this head -----------------------------------------------
-    const int xf = p.flags;  // timing experiments
+    // timing experiments (a build with -DASRFE_ATTN_TIMING; results are wrong when a bit is set):
+    // 1 no FSMN phase, 2 no PV product, 4 no QK product, 8 no K / V prefetch
+#ifdef ASRFE_ATTN_TIMING
+    const int xf = p.flags;
+#else
+    constexpr int xf = 0;
+#endif
     if (!(xf & 1)) {
         // stage row rr (0..143) = V row qb - 5 + rr, clamped into the utterance's rows (masked when used)
         const uint32_t fst = __builtin_amdgcn_readfirstlane(smem_base + kFsmnStage + wave * 1024);

@@ -1,4 +1,4 @@
-// Parameters of the bf16 MFMA GEMM (gemm.hip).
+// Parameters of the 16-bit (fp16 / bf16 operands, fp32 accumulate) MFMA GEMM (gemm.hip).
 #pragma once
 
 #include "common.h"
@@ -6,15 +6,15 @@
 namespace asrfe {
 
 enum GemmEpilogue {
-    EPI_BF16 = 0,       // out bf16 = acc + bias
-    EPI_BF16_RELU = 1,  // out bf16 = relu(acc + bias)
+    EPI_BF16 = 0,       // out 16-bit = acc + bias
+    EPI_BF16_RELU = 1,  // out 16-bit = relu(acc + bias)
     EPI_F32_ADD = 2,    // out f32  = acc + bias (+ add16) (+ add32)
 };
 
 struct GemmParams {
-    const uint16_t* A;  // bf16 [M][lda]
+    const uint16_t* A;  // 16-bit [M][lda]
     int lda;
-    const uint16_t* W;  // bf16 [N][ldw]
+    const uint16_t* W;  // 16-bit [N][ldw]
     int ldw;
     const float* bias;  // [N]
     int M, N, K;
@@ -25,7 +25,7 @@ struct GemmParams {
     const float* add32;     // optional f32 [M][ld32]
     int ld32;
     int n_tiles_m, n_tiles_n;  // filled by launch_gemm
-    int flags;                 // bit 0: skip the epilogue stores (timing experiments)
+    int flags;                 // bit 0: skip the epilogue stores (timing experiments); bits 4-5: store cache policy
 };
 
 int32_t launch_gemm(asrfe_ctx* ctx, const GemmParams& p, int epi, hipStream_t s);
