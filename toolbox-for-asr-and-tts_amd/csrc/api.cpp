@@ -137,6 +137,7 @@ static int32_t check_config(const asrfe_config& c, std::string& why) {
     }
     if (c.n_mels < 1 || c.n_mels > kMaxMels) { why = "n_mels must be in 1..80"; return ASRFE_ERR_BAD_ARG; }
     if (c.lfr_m < 1 || c.lfr_n < 1 || c.lfr_m > 16) { why = "bad lfr_m / lfr_n"; return ASRFE_ERR_BAD_ARG; }
+    if (c.lfr_m * c.n_mels > asrfe::kMaxFeatDim) { why = "lfr_m * n_mels must be <= 640"; return ASRFE_ERR_BAD_ARG; }
     if (c.preemph != 0.97f) { why = "only pre-emphasis 0.97 is built"; return ASRFE_ERR_BAD_ARG; }
     if (c.enc_output_size != 512 || c.enc_heads != 4) {
         why = "only enc_output_size 512 with 4 heads (d_k 128) kernels are built";
@@ -204,7 +205,7 @@ extern "C" int32_t asrfe_create(const asrfe_config* cfg, asrfe_ctx** out) {
     if ((rc = upload(ctx, t256, &ctx->tab.tw256))) return fail(rc);
     if ((rc = upload(ctx, t512, &ctx->tab.tw512))) return fail(rc);
 
-    // mel filters: per-lane CSR, zero-padded to the widest filter of each group of 16
+    // mel filters: per-lane CSR, zero-padded to the widest filter of each group of 16 rounded up to 4 terms
     std::vector<double> banks;
     build_mel_banks(*cfg, banks);
     const int nb = kNc;
@@ -230,6 +231,7 @@ extern "C" int32_t asrfe_create(const asrfe_config* cfg, asrfe_ctx** out) {
     for (int g = 0; g < kMelGroups; ++g) {
         int gw = 0;
         for (int l = 0; l < 16; ++l) gw = std::max(gw, width[g * 16 + l]);
+        gw = (gw + 3) / 4 * 4;
         ctx->tab.mel_gw[g] = gw;
         ctx->tab.mel_go[g] = total;
         total += gw;
@@ -245,9 +247,11 @@ extern "C" int32_t asrfe_create(const asrfe_config* cfg, asrfe_ctx** out) {
             const int m = g * 16 + l;
             msb[g * 16 + l] = start[g * 16 + l];
             if (m >= cfg->n_mels) continue;
-            for (int j = 0; j < width[g * 16 + l]; ++j)
-                mw[(ctx->tab.mel_go[g] + j) * 16 + l] =
+            for (int j = 0; j < width[g * 16 + l]; ++j) {
+                const int term = ctx->tab.mel_go[g] + j;  // chunk term / 4, lane l, element term % 4
+                mw[((term / 4) * 16 + l) * 4 + term % 4] =
                     static_cast<float>(0.25 * banks[static_cast<size_t>(m) * nb + start[g * 16 + l] + j]);
+            }
         }
     if ((rc = upload(ctx, mw, &ctx->tab.mel_w))) return fail(rc);
     if ((rc = upload(ctx, msb, &ctx->tab.mel_sb))) return fail(rc);

@@ -17,6 +17,7 @@ constexpr int kFrameShift = 160;
 constexpr int kNfft = 512;
 constexpr int kNc = 256;          // complex points of the packed real FFT
 constexpr int kMaxMels = 80;
+constexpr int kMaxFeatDim = 640;  // lfr_m * n_mels the fused frontend kernel keeps CMVN constants for
 constexpr int kMelGroups = 5;     // filters handled per lane: m = lane + 16 * g
 constexpr int kMelMaxTerms = 64;  // sum over groups of the widest filter in each group
 constexpr int kWinPad = 416;      // 13 * 32 window slots, zero past kFrameLen
@@ -26,10 +27,10 @@ struct FrontendTables {
     float* window;    // [kWinPad]
     float2* tw256;    // [16][16]  W256^(n2*k1), row n2
     float2* tw512;    // [129]     W512^k
-    float* mel_w;     // [kMelMaxTerms][16] weights, term-major, lane-minor (includes the 1/4 power scale)
+    float* mel_w;     // [kMelMaxTerms / 4][16][4] weights: 4-term chunk, lane, term (includes the 1/4 power scale)
     int32_t* mel_sb;  // [kMelGroups][16] first bin of filter lane + 16 g
-    int32_t mel_gw[kMelGroups];  // widest filter of each group (terms)
-    int32_t mel_go[kMelGroups];  // first term row of each group in mel_w
+    int32_t mel_gw[kMelGroups];  // widest filter of each group, rounded up to a multiple of 4 terms
+    int32_t mel_go[kMelGroups];  // first term of each group in mel_w (a multiple of 4)
     float* cmvn_shift;  // [lfr_m * n_mels]
     float* cmvn_scale;
 };

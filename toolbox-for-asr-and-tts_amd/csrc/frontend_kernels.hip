@@ -10,7 +10,11 @@
 //     W256^(n2 k1), the 16 lanes transpose through LDS, lane k1 transforms over n2 and ends
 //     with Z[k1 + 16 k2].  One pass over LDS pairs Z[k] with Z[256-k] to get 4|X[k]|^2.
 //   * mel: each lane sums the 5 filters m = lane + 16 g from the power row in LDS; the weight
-//     table is zero-padded per group so the trip counts are wave-uniform.
+//     table is zero-padded per group to a wave-uniform multiple of 4 terms and read 4 terms at a
+//     time.  For the standard 80-filter layout the trip counts are compile-time constants, so
+//     every LDS read of the stage is in flight before the first multiply waits for one.
+#include <type_traits>
+
 #include "common.h"
 
 namespace asrfe {
@@ -22,8 +26,12 @@ constexpr int kFramesPerBlock = kFramesPerWave * kGroupsPerWave * kWavesPerBlock
 constexpr int kStageSamples = kFrameShift * (kFramesPerWave - 1) + kFrameLen;       // 880
 constexpr int kStageChunks = kStageSamples / 8;                                     // 110
 constexpr int kExRow = 36;                             // floats per exchange row (16 complex + 16 B pad)
-constexpr int kFrameLds = 16 * kExRow;                 // 576 floats per frame
-constexpr int kWaveLds = kFramesPerWave * kFrameLds;   // 2304 floats = 9216 B per wave
+// Floats per frame region: 16 exchange rows plus 32.  The LDS serves 8-byte accesses 32 lanes (two frames) at a
+// time over 64 banks, so neighbouring frames must lie 32 banks apart; 4-byte accesses go 32 lanes at a time over
+// 32 banks, so the power row, the only thing accessed that way, is shifted by 16 floats in every other frame.
+constexpr int kFrameLds = 16 * kExRow + 32;            // 608
+constexpr int kWaveLds = kFramesPerWave * kFrameLds;   // 2432 floats = 9728 B per wave
+constexpr int kConstFloats = (13 + 16 + 8) * 16 * 2;   // window and twiddle pairs kept in LDS
 static_assert(kWaveLds >= kStageSamples + 16, "staging area must fit the wave region");
 static_assert(kFrameLds >= 2 * kNc, "Z row must fit the frame region");
 
@@ -33,61 +41,109 @@ __device__ __forceinline__ void wave_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-// 4-point forward DFT in place, natural output order.
-__device__ __forceinline__ void dft4(float& r0, float& i0, float& r1, float& i1, float& r2, float& i2,
-                                     float& r3, float& i3) {
-    const float ar = r0 + r2, ai = i0 + i2;
-    const float br = r0 - r2, bi = i0 - i2;
-    const float cr = r1 + r3, ci = i1 + i3;
-    const float dr = r1 - r3, di = i1 - i3;
-    r0 = ar + cr; i0 = ai + ci;
-    r2 = ar - cr; i2 = ai - ci;
-    r1 = br + di; i1 = bi - dr;
-    r3 = br - di; i3 = bi + dr;
+// Sum over the 16 lanes of a DPP row (= one frame), result in every lane: lane exchanges stay in the VALU.
+__device__ __forceinline__ float row16_sum(float v) {
+    auto dpp_add = [](float x, auto ctrl) {
+        const int y = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), decltype(ctrl)::value, 0xf, 0xf, false);
+        return x + __builtin_bit_cast(float, y);
+    };
+    v = dpp_add(v, std::integral_constant<int, 0xB1>{});   // quad_perm [1,0,3,2]
+    v = dpp_add(v, std::integral_constant<int, 0x4E>{});   // quad_perm [2,3,0,1]
+    v = dpp_add(v, std::integral_constant<int, 0x141>{});  // row_half_mirror
+    v = dpp_add(v, std::integral_constant<int, 0x140>{});  // row_mirror
+    return v;
 }
 
-__device__ __forceinline__ void cmul(float& r, float& i, const float wr, const float wi) {
-    const float tr = r * wr - i * wi;
-    i = r * wi + i * wr;
-    r = tr;
+// 4-term chunks per mel group (filters lane + 16 g) of the standard layout: 80 filters, 20 Hz .. 8 kHz, 512-point FFT
+__device__ __host__ constexpr int std_mel_chunks(int g) { return g == 0 ? 1 : g == 1 ? 1 : g == 2 ? 2 : g == 3 ? 3 : 4; }
+__device__ __host__ constexpr int std_mel_first(int g) { return g == 0 ? 0 : g == 1 ? 1 : g == 2 ? 2 : g == 3 ? 4 : 7; }
+
+// Complex numbers travel as packed fp32 pairs (re, im) through v_pk_add / v_pk_mul / v_pk_fma_f32.  The half
+// selectors (op_sel, op_sel_hi) and sign bits (neg_lo, neg_hi) of those instructions do the swaps and negations of
+// complex arithmetic for free, which the compiler does not exploit on its own: hence the inline assembly.
+typedef float v2f __attribute__((ext_vector_type(2)));
+
+// Compile-time twiddles sit in SGPR pairs (one scalar operand per VOP3P instruction is allowed).
+struct ctw { v2f w; };
+
+// z * w = (zr wr - zi wi, zr wi + zi wr): t = (-zi wi, zi wr), then r = (zr wr, zr wi) + t
+__device__ __forceinline__ v2f cmul(const v2f z, const v2f w) {
+    v2f t, r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[1,0] neg_lo:[1,0]" : "=v"(t) : "v"(z), "v"(w));
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[0,1,1]" : "=v"(r) : "v"(z), "v"(w), "v"(t));
+    return r;
+}
+__device__ __forceinline__ v2f cmul(const v2f z, const ctw c) {
+    v2f t, r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[1,0] neg_lo:[1,0]" : "=v"(t) : "v"(z), "s"(c.w));
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[0,1,1]" : "=v"(r) : "v"(z), "s"(c.w), "v"(t));
+    return r;
+}
+// (-i z) * w = (zi wr + zr wi, zi wi - zr wr): t = (zr wi, -zr wr), then r = (zi wr, zi wi) + t
+__device__ __forceinline__ v2f cmul_neg_i(const v2f z, const v2f w) {
+    v2f t, r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[0,0] neg_hi:[1,0]" : "=v"(t) : "v"(z), "v"(w));
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "=v"(r) : "v"(z), "v"(w), "v"(t));
+    return r;
+}
+// b + (-i) e = (br + ei, bi - er)  and  b - (-i) e = (br - ei, bi + er)
+__device__ __forceinline__ v2f add_neg_i(const v2f b, const v2f e) {
+    v2f r;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(r) : "v"(b), "v"(e));
+    return r;
+}
+__device__ __forceinline__ v2f sub_neg_i(const v2f b, const v2f e) {
+    v2f r;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(r) : "v"(b), "v"(e));
+    return r;
+}
+// a + conj(b) and a - conj(b)
+__device__ __forceinline__ v2f add_conj(const v2f a, const v2f b) {
+    v2f r;
+    asm("v_pk_add_f32 %0, %1, %2 neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ v2f sub_conj(const v2f a, const v2f b) {
+    v2f r;
+    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
+// 4-point forward DFT in place, natural output order.
+__device__ __forceinline__ void dft4(v2f& z0, v2f& z1, v2f& z2, v2f& z3) {
+    const v2f a = z0 + z2, b = z0 - z2, c = z1 + z3, e = z1 - z3;
+    z0 = a + c;
+    z2 = a - c;
+    z1 = add_neg_i(b, e);
+    z3 = sub_neg_i(b, e);
 }
 
 // 16-point forward DFT in registers.  Input x[n] at index n; output X[k] at index 4 (k & 3) + (k >> 2).
-__device__ __forceinline__ void dft16(float (&re)[16], float (&im)[16]) {
+__device__ __forceinline__ void dft16(v2f (&z)[16]) {
     constexpr float c1 = 0.92387953251128674f;  // cos(pi/8)
     constexpr float s1 = 0.38268343236508977f;  // sin(pi/8)
     constexpr float h = 0.70710678118654752f;
-    float yr[16], yi[16];
+    v2f y[16];
 #pragma unroll
     for (int b = 0; b < 4; ++b) {
-        float r0 = re[b], i0 = im[b], r1 = re[4 + b], i1 = im[4 + b];
-        float r2 = re[8 + b], i2 = im[8 + b], r3 = re[12 + b], i3 = im[12 + b];
-        dft4(r0, i0, r1, i1, r2, i2, r3, i3);
-        yr[b] = r0; yi[b] = i0;
-        yr[4 + b] = r1; yi[4 + b] = i1;
-        yr[8 + b] = r2; yi[8 + b] = i2;
-        yr[12 + b] = r3; yi[12 + b] = i3;
+        v2f t0 = z[b], t1 = z[4 + b], t2 = z[8 + b], t3 = z[12 + b];
+        dft4(t0, t1, t2, t3);
+        y[b] = t0; y[4 + b] = t1; y[8 + b] = t2; y[12 + b] = t3;
     }
     // y[4 c + b] *= W16^(b c)
-    cmul(yr[5], yi[5], c1, -s1);    // b1 c1 : W^1
-    cmul(yr[6], yi[6], h, -h);      // b2 c1 : W^2
-    cmul(yr[7], yi[7], s1, -c1);    // b3 c1 : W^3
-    cmul(yr[9], yi[9], h, -h);      // b1 c2 : W^2
-    cmul(yr[10], yi[10], 0.f, -1.f);  // b2 c2 : W^4
-    cmul(yr[11], yi[11], -h, -h);   // b3 c2 : W^6
-    cmul(yr[13], yi[13], s1, -c1);  // b1 c3 : W^3
-    cmul(yr[14], yi[14], -h, -h);   // b2 c3 : W^6
-    cmul(yr[15], yi[15], -c1, s1);  // b3 c3 : W^9
+    y[5] = cmul(y[5], ctw{{c1, -s1}});    // b1 c1 : W^1
+    y[6] = cmul(y[6], ctw{{h, -h}});      // b2 c1 : W^2
+    y[7] = cmul(y[7], ctw{{s1, -c1}});    // b3 c1 : W^3
+    y[9] = cmul(y[9], ctw{{h, -h}});      // b1 c2 : W^2
+    y[10] = cmul(y[10], ctw{{0.0f, -1.0f}});  // b2 c2 : W^4 = -i
+    y[11] = cmul(y[11], ctw{{-h, -h}});   // b3 c2 : W^6
+    y[13] = cmul(y[13], ctw{{s1, -c1}});  // b1 c3 : W^3
+    y[14] = cmul(y[14], ctw{{-h, -h}});   // b2 c3 : W^6
+    y[15] = cmul(y[15], ctw{{-c1, s1}});  // b3 c3 : W^9
 #pragma unroll
-    for (int c = 0; c < 4; ++c) {
-        dft4(yr[4 * c], yi[4 * c], yr[4 * c + 1], yi[4 * c + 1], yr[4 * c + 2], yi[4 * c + 2], yr[4 * c + 3],
-             yi[4 * c + 3]);
-    }
+    for (int c = 0; c < 4; ++c) dft4(y[4 * c], y[4 * c + 1], y[4 * c + 2], y[4 * c + 3]);
 #pragma unroll
-    for (int k = 0; k < 16; ++k) {
-        re[k] = yr[k];
-        im[k] = yi[k];
-    }
+    for (int k = 0; k < 16; ++k) z[k] = y[k];
 }
 
 __device__ __forceinline__ constexpr int pos16(int k) { return 4 * (k & 3) + (k >> 2); }
@@ -99,45 +155,50 @@ __device__ __forceinline__ float pcm_to_kaldi<int16_t>(int16_t v) { return stati
 template <>
 __device__ __forceinline__ float pcm_to_kaldi<float>(float v) { return v * 32768.0f; }
 
-// Loads samples [s, s + 8) of one clip as Kaldi-scaled floats, zero past the clip's end.
+// Eight consecutive samples as they lie in memory (one or two 16-byte loads), and their Kaldi-scaled floats.
 template <typename PcmT>
-__device__ __forceinline__ void load8(const PcmT* __restrict__ row, int64_t s, int64_t len, bool vec_ok,
-                                      float (&out)[8]) {
-    if (vec_ok && s + 8 <= len) {
-        if constexpr (sizeof(PcmT) == 2) {
-            const int4 raw = *reinterpret_cast<const int4*>(row + s);
-            const int w[4] = {raw.x, raw.y, raw.z, raw.w};
+struct Raw8;
+template <>
+struct Raw8<int16_t> {
+    int4 q;
+    __device__ __forceinline__ void load(const int16_t* p) { q = *reinterpret_cast<const int4*>(p); }
+    __device__ __forceinline__ void get(float (&out)[8]) const {
+        const int w[4] = {q.x, q.y, q.z, q.w};
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                out[2 * j] = static_cast<float>(static_cast<int16_t>(w[j] & 0xffff));
-                out[2 * j + 1] = static_cast<float>(w[j] >> 16);
-            }
-        } else {
-            const float4 a = *reinterpret_cast<const float4*>(row + s);
-            const float4 b = *reinterpret_cast<const float4*>(row + s + 4);
-            out[0] = a.x * 32768.0f; out[1] = a.y * 32768.0f; out[2] = a.z * 32768.0f; out[3] = a.w * 32768.0f;
-            out[4] = b.x * 32768.0f; out[5] = b.y * 32768.0f; out[6] = b.z * 32768.0f; out[7] = b.w * 32768.0f;
+        for (int j = 0; j < 4; ++j) {
+            out[2 * j] = static_cast<float>(static_cast<int16_t>(w[j] & 0xffff));
+            out[2 * j + 1] = static_cast<float>(w[j] >> 16);
         }
-    } else {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) out[j] = (s + j < len) ? pcm_to_kaldi<PcmT>(row[s + j]) : 0.0f;
     }
-}
+};
+template <>
+struct Raw8<float> {
+    float4 a, b;
+    __device__ __forceinline__ void load(const float* p) {
+        a = *reinterpret_cast<const float4*>(p);
+        b = *reinterpret_cast<const float4*>(p + 4);
+    }
+    __device__ __forceinline__ void get(float (&out)[8]) const {
+        out[0] = a.x * 32768.0f; out[1] = a.y * 32768.0f; out[2] = a.z * 32768.0f; out[3] = a.w * 32768.0f;
+        out[4] = b.x * 32768.0f; out[5] = b.y * 32768.0f; out[6] = b.z * 32768.0f; out[7] = b.w * 32768.0f;
+    }
+};
 
 __device__ __forceinline__ uint16_t f32_to_bf16(float v) {
     return __builtin_bit_cast(uint16_t, static_cast<__bf16>(v));
 }
 
-// Writes one log-mel value of frame t into every LFR/CMVN feature slot that holds it.
-// Row i, slot j holds frame clamp(n i + j - left, 0, T-1), left = (m-1)/2; rows >= rows_out are dropped.
+// Writes the log-mel values mel[g] (filter l + 16 g) of frame t into every LFR/CMVN feature slot that holds them.
+// Row i, slot j holds frame clamp(n i + j - left, 0, T-1), left = (m-1)/2; rows >= rows_out are dropped.  No global
+// load happens here, so a wave never waits on its earlier stores or on the samples fetched ahead.
 template <bool OUT_BF16>
-__device__ __forceinline__ void lfr_scatter(void* __restrict__ feats_b, int t, int T, int Tp, int rows_out, int mel,
-                                            int n_mels, int lfr_m, int lfr_n, const float* __restrict__ shift,
-                                            const float* __restrict__ scale, float v) {
+__device__ __forceinline__ void lfr_scatter(void* __restrict__ feats_b, int t, int T, int Tp, int rows_out, int l,
+                                            int n_mels, int lfr_m, int lfr_n, const float2* cmvn,
+                                            const float (&mel)[kMelGroups]) {
     const int left = (lfr_m - 1) / 2;
     const int dim = lfr_m * n_mels;
     const int a = t + left - (lfr_m - 1);            // first row: n i >= a
-    int i_lo = a <= 0 ? 0 : (a + lfr_n - 1) / lfr_n;
+    const int i_lo = a <= 0 ? 0 : (a + lfr_n - 1) / lfr_n;
     int i_hi = (t == T - 1) ? Tp - 1 : (t + left) / lfr_n;  // the last frame also fills every slot past the end
     if (i_hi > rows_out - 1) i_hi = rows_out - 1;
     for (int i = i_lo; i <= i_hi; ++i) {
@@ -147,21 +208,32 @@ __device__ __forceinline__ void lfr_scatter(void* __restrict__ feats_b, int t, i
         if (j_lo < 0) j_lo = 0;
         if (j_hi > lfr_m - 1) j_hi = lfr_m - 1;
         for (int j = j_lo; j <= j_hi; ++j) {
-            const int col = j * n_mels + mel;
-            const float y = (v + shift[col]) * scale[col];
-            if constexpr (OUT_BF16)
-                reinterpret_cast<uint16_t*>(feats_b)[static_cast<int64_t>(i) * dim + col] = f32_to_bf16(y);
-            else
-                reinterpret_cast<float*>(feats_b)[static_cast<int64_t>(i) * dim + col] = y;
+            const int col0 = j * n_mels + l;
+            const int64_t o = static_cast<int64_t>(i) * dim + col0;
+#pragma unroll
+            for (int g = 0; g < kMelGroups; ++g) {
+                if (l + 16 * g < n_mels) {
+                    const float2 ss = cmvn[col0 + 16 * g];  // (shift, scale), in LDS
+                    const float y = (mel[g] + ss.x) * ss.y;
+                    if constexpr (OUT_BF16) reinterpret_cast<uint16_t*>(feats_b)[o + 16 * g] = f32_to_bf16(y);
+                    else reinterpret_cast<float*>(feats_b)[o + 16 * g] = y;
+                }
+            }
         }
     }
 }
 
-template <typename PcmT, bool FUSED, bool OUT_BF16>
-__global__ __launch_bounds__(kWavesPerBlock * 64) void fbank_kernel(const FbankParams p) {
-    __shared__ __attribute__((aligned(16))) float lds[kWavesPerBlock * kWaveLds + kMelMaxTerms * 16 + kMelGroups * 16];
-    float* mel_w = lds + kWavesPerBlock * kWaveLds;
+template <typename PcmT, bool FUSED, bool OUT_BF16, bool STD_MEL>
+__global__ __launch_bounds__(kWavesPerBlock * 64, 3) void fbank_kernel(const FbankParams p) {
+    __shared__ __attribute__((aligned(16))) float lds[kWavesPerBlock * kWaveLds + kMelMaxTerms * 16 + kMelGroups * 16 +
+                                                      kConstFloats + (FUSED ? 2 * kMaxFeatDim : 0)];
+    float* mel_w = lds + kWavesPerBlock * kWaveLds;  // float4 [chunk][lane]
     int* mel_sb = reinterpret_cast<int*>(mel_w + kMelMaxTerms * 16);
+    // per-lane constants as (x, y) pairs, [row][lane of the frame]: 13 window rows, 16 + 8 twiddle rows
+    v2f* c_win = reinterpret_cast<v2f*>(mel_sb + kMelGroups * 16);
+    v2f* c_twa = c_win + 13 * 16;
+    v2f* c_twp = c_twa + 16 * 16;
+    float2* cmvn = reinterpret_cast<float2*>(c_twp + 8 * 16);  // (shift, scale) per feature column (fused mode)
 
     const int tid = threadIdx.x;
     const int wave = tid >> 6;
@@ -172,7 +244,6 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void fbank_kernel(const FbankP
 
     for (int i = tid; i < kMelMaxTerms * 16; i += kWavesPerBlock * 64) mel_w[i] = p.tab.mel_w[i];
     for (int i = tid; i < kMelGroups * 16; i += kWavesPerBlock * 64) mel_sb[i] = p.tab.mel_sb[i];
-    __syncthreads();
 
     const int64_t len = p.pcm_lens[b];
     const int T = len < kFrameLen ? 0 : 1 + static_cast<int>((len - kFrameLen) / kFrameShift);
@@ -184,26 +255,51 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void fbank_kernel(const FbankP
     const PcmT* __restrict__ row = reinterpret_cast<const PcmT*>(p.pcm) + static_cast<int64_t>(b) * p.pcm_stride;
     const bool vec_ok = p.aligned16 != 0;
 
-    // per-lane constants
-    float w0[13], w1[13];
-#pragma unroll
-    for (int n1 = 0; n1 < 13; ++n1) {
-        w0[n1] = p.tab.window[32 * n1 + 2 * l];
-        w1[n1] = p.tab.window[32 * n1 + 2 * l + 1];
+    for (int i = tid; i < 13 * 16; i += kWavesPerBlock * 64) {
+        const int n1 = i >> 4, ll = i & 15;
+        c_win[i] = v2f{p.tab.window[32 * n1 + 2 * ll], p.tab.window[32 * n1 + 2 * ll + 1]};
     }
-    float2 twa[16];
-#pragma unroll
-    for (int k1 = 0; k1 < 16; ++k1) twa[k1] = p.tab.tw256[l * 16 + k1];
-    float2 twp[8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) twp[i] = p.tab.tw512[1 + l + 16 * i];
+    for (int i = tid; i < 16 * 16; i += kWavesPerBlock * 64) {
+        const float2 tw = p.tab.tw256[(i & 15) * 16 + (i >> 4)];  // row k1, lane n2
+        c_twa[i] = v2f{tw.x, tw.y};
+    }
+    for (int i = tid; i < 8 * 16; i += kWavesPerBlock * 64) {
+        const float2 tw = p.tab.tw512[1 + (i & 15) + 16 * (i >> 4)];
+        c_twp[i] = v2f{tw.x, tw.y};
+    }
+    if constexpr (FUSED) {
+        for (int i = tid; i < p.lfr_m * p.n_mels; i += kWavesPerBlock * 64)
+            cmvn[i] = make_float2(p.tab.cmvn_shift[i], p.tab.cmvn_scale[i]);
+    }
+    __syncthreads();
 
     float* wl = lds + wave * kWaveLds;        // this wave's region
     float* fl = wl + f * kFrameLds;           // this frame's region
+    float* prow = fl + 16 * (f & 1);          // its power row
     const float preemph = 0.97f;
 
+    // Samples [160 t0, 160 t0 + 880) of a group are fetched one group ahead, 8 per lane and pass, and wait in
+    // registers while the previous group is computed.  Chunks that cross the end of the clip, and clips whose
+    // address does not allow 16-byte loads, are read sample by sample when the group is staged.
+    const int t_lim = T < p.t_max ? T : p.t_max;
+    auto group_t0 = [&](int g) { return blockIdx.x * kFramesPerBlock + (g * kWavesPerBlock + wave) * kFramesPerWave; };
+    auto fast_chunk = [&](int t0, int c) {
+        return vec_ok && c < kStageChunks && static_cast<int64_t>(kFrameShift) * t0 + 8 * c + 8 <= len;
+    };
+    Raw8<PcmT> raw[2];
+    auto prefetch = [&](int g) {
+        const int t0 = group_t0(g);
+        if (g >= kGroupsPerWave || t0 >= t_lim) return;
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const int c = lane + 64 * r;
+            if (fast_chunk(t0, c)) raw[r].load(row + static_cast<int64_t>(kFrameShift) * t0 + 8 * c);
+        }
+    };
+    prefetch(0);
+
     for (int g = 0; g < kGroupsPerWave; ++g) {
-        const int t0 = blockIdx.x * kFramesPerBlock + (g * kWavesPerBlock + wave) * kFramesPerWave;
+        const int t0 = group_t0(g);
         if (t0 >= p.t_max) break;  // wave-uniform
         const int t = t0 + f;
         if (t0 >= T) {
@@ -237,107 +333,115 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void fbank_kernel(const FbankP
             const int c = lane + 64 * r;
             if (c < kStageChunks) {
                 float v[8];
-                load8<PcmT>(row, s_base + 8 * c, len, vec_ok, v);
+                if (fast_chunk(t0, c)) {
+                    raw[r].get(v);
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const int64_t si = s_base + 8 * c + j;
+                        v[j] = si < len ? pcm_to_kaldi<PcmT>(row[si]) : 0.0f;
+                    }
+                }
                 *reinterpret_cast<float4*>(wl + 8 * c) = make_float4(v[0], v[1], v[2], v[3]);
                 *reinterpret_cast<float4*>(wl + 8 * c + 4) = make_float4(v[4], v[5], v[6], v[7]);
             }
         }
+        prefetch(g + 1);
         wave_sync();
 
         // ---- frame samples -> DC removal, pre-emphasis, window ----------------------------------
-        float re[16], im[16];
+        v2f z[16];
         {
             const float* xs = wl + kFrameShift * f;
-            float sr[13], si[13], pv[13];
-            float sum = 0.0f;
+            v2f sv[13];
+            float pv[13];
+            v2f sum2 = v2f{0.0f, 0.0f};
 #pragma unroll
             for (int n1 = 0; n1 < 13; ++n1) {
                 const int i0 = 32 * n1 + 2 * l;
                 const float2 v = *reinterpret_cast<const float2*>(xs + i0);
                 const float pr = xs[i0 > 0 ? i0 - 1 : 0];
                 const bool ok = (n1 < 12) || (l < 8);  // sample index < 400
-                sr[n1] = ok ? v.x : 0.0f;
-                si[n1] = ok ? v.y : 0.0f;
+                sv[n1] = ok ? v2f{v.x, v.y} : v2f{0.0f, 0.0f};
                 pv[n1] = ok ? pr : 0.0f;
-                sum += sr[n1] + si[n1];
+                sum2 += sv[n1];
             }
-            sum += __shfl_xor(sum, 1);
-            sum += __shfl_xor(sum, 2);
-            sum += __shfl_xor(sum, 4);
-            sum += __shfl_xor(sum, 8);
-            const float mean = sum / 400.0f;
+            const float mean = row16_sum(sum2.x + sum2.y) * (1.0f / 400.0f);
+            // (a, c) = samples - mean; pre-emphasis subtracts 0.97 x the previous sample, (q, a); then the window.
+            // Slots past sample 399 hold zeros times a zero window entry.
 #pragma unroll
             for (int n1 = 0; n1 < 13; ++n1) {
-                const float a = sr[n1] - mean;
-                const float c = si[n1] - mean;
-                const float q = pv[n1] - mean;
-                re[n1] = (a - preemph * q) * w0[n1];
-                im[n1] = (c - preemph * a) * w1[n1];
+                const v2f ac = sv[n1] - mean;
+                const v2f qa = v2f{pv[n1], sv[n1].x} - mean;
+                z[n1] = (ac - preemph * qa) * c_win[n1 * 16 + l];
             }
-            re[13] = re[14] = re[15] = 0.0f;
-            im[13] = im[14] = im[15] = 0.0f;
+            z[13] = z[14] = z[15] = v2f{0.0f, 0.0f};
         }
         wave_sync();  // staged samples consumed; the region becomes the exchange buffer
 
         // ---- 256-point complex FFT, 16 x 16 --------------------------------------------------
-        dft16(re, im);
+        dft16(z);
 #pragma unroll
         for (int k1 = 0; k1 < 16; ++k1) {
-            float ar = re[pos16(k1)], ai = im[pos16(k1)];
-            if (k1 > 0) cmul(ar, ai, twa[k1].x, twa[k1].y);
-            *reinterpret_cast<float2*>(fl + k1 * kExRow + 2 * l) = make_float2(ar, ai);
+            v2f a = z[pos16(k1)];
+            if (k1 > 0) a = cmul(a, c_twa[k1 * 16 + l]);
+            *reinterpret_cast<v2f*>(fl + k1 * kExRow + 2 * l) = a;
         }
         wave_sync();
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const float4 q = *reinterpret_cast<const float4*>(fl + l * kExRow + 4 * j);
-            re[2 * j] = q.x; im[2 * j] = q.y;
-            re[2 * j + 1] = q.z; im[2 * j + 1] = q.w;
+            z[2 * j] = v2f{q.x, q.y};
+            z[2 * j + 1] = v2f{q.z, q.w};
         }
-        dft16(re, im);
+        dft16(z);
         wave_sync();
 #pragma unroll
-        for (int k2 = 0; k2 < 16; ++k2)
-            *reinterpret_cast<float2*>(fl + 2 * (l + 16 * k2)) = make_float2(re[pos16(k2)], im[pos16(k2)]);
+        for (int k2 = 0; k2 < 16; ++k2) *reinterpret_cast<v2f*>(fl + 2 * (l + 16 * k2)) = z[pos16(k2)];
         wave_sync();
 
         // ---- pair Z[k], Z[256-k] -> 4 |X[k]|^2, 4 |X[256-k]|^2 ---------------------------------
-        float pk[8], pq[8];
+        //      X[k] = E + W O, X[256-k]* = E - W O with E = (Z[k] + Z[256-k]*) , O = -i (Z[k] - Z[256-k]*)
+        v2f pw[8];  // (power at k, power at 256 - k)
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const int k = 1 + l + 16 * i;
-            const float2 zk = *reinterpret_cast<const float2*>(fl + 2 * k);
-            const float2 zq = *reinterpret_cast<const float2*>(fl + 2 * (kNc - k));
-            const float er = zk.x + zq.x, ei = zk.y - zq.y;
-            const float orr = zk.y + zq.y, oi = zq.x - zk.x;
-            const float tr = twp[i].x * orr - twp[i].y * oi;
-            const float ti = twp[i].x * oi + twp[i].y * orr;
-            const float x1r = er + tr, x1i = ei + ti;
-            const float x2r = er - tr, x2i = ei - ti;
-            pk[i] = x1r * x1r + x1i * x1i;
-            pq[i] = x2r * x2r + x2i * x2i;
+            const v2f zk = *reinterpret_cast<const v2f*>(fl + 2 * k);
+            const v2f zq = *reinterpret_cast<const v2f*>(fl + 2 * (kNc - k));
+            const v2f e = add_conj(zk, zq);
+            const v2f t = cmul_neg_i(sub_conj(zk, zq), c_twp[i * 16 + l]);
+            const v2f x1 = e + t, x2 = e - t;
+            const v2f s1 = x1 * x1, s2 = x2 * x2;
+            pw[i] = v2f{s1.x + s1.y, s2.x + s2.y};
         }
         wave_sync();
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const int k = 1 + l + 16 * i;
-            fl[k] = pk[i];
-            fl[kNc - k] = pq[i];
+            prow[k] = pw[i].x;
+            prow[kNc - k] = pw[i].y;
         }
+        // the padded tails of the filters run past the last bin: zero weights meet zeros there
+        prow[kNc + l] = 0.0f;
+        prow[kNc + 16 + l] = 0.0f;
         wave_sync();
 
         // ---- mel + log --------------------------------------------------------------------------
         float mel[kMelGroups];
 #pragma unroll
         for (int gi = 0; gi < kMelGroups; ++gi) {
-            const int sb = mel_sb[gi * 16 + l];
-            const int gw = p.tab.mel_gw[gi];
-            const float* wrow = mel_w + p.tab.mel_go[gi] * 16 + l;
+            const float* pr = prow + mel_sb[gi * 16 + l];
+            const int nc = STD_MEL ? std_mel_chunks(gi) : p.tab.mel_gw[gi] >> 2;
+            const float4* wq = reinterpret_cast<const float4*>(mel_w) +
+                               (STD_MEL ? std_mel_first(gi) : p.tab.mel_go[gi] >> 2) * 16 + l;
             float acc = 0.0f;
-            for (int j = 0; j < gw; ++j) {
-                int k = sb + j;
-                k = k > kNc - 1 ? kNc - 1 : k;
-                acc = fmaf(wrow[j * 16], fl[k], acc);
+#pragma unroll
+            for (int c = 0; c < nc; ++c) {
+                const float4 w = wq[c * 16];
+                acc = fmaf(w.x, pr[4 * c], acc);
+                acc = fmaf(w.y, pr[4 * c + 1], acc);
+                acc = fmaf(w.z, pr[4 * c + 2], acc);
+                acc = fmaf(w.w, pr[4 * c + 3], acc);
             }
             mel[gi] = __logf(fmaxf(acc, 1.1920929e-07f));
         }
@@ -354,13 +458,8 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void fbank_kernel(const FbankP
                 const int dim = p.lfr_m * p.n_mels;
                 char* fb = reinterpret_cast<char*>(p.feats) +
                            static_cast<int64_t>(b) * p.tp_max * dim * (OUT_BF16 ? 2 : 4);
-#pragma unroll
-                for (int gi = 0; gi < kMelGroups; ++gi) {
-                    const int m = l + 16 * gi;
-                    if (m < p.n_mels)
-                        lfr_scatter<OUT_BF16>(fb, t, T, Tp, Tp < p.tp_max ? Tp : p.tp_max, m, p.n_mels, p.lfr_m, p.lfr_n, p.tab.cmvn_shift,
-                                              p.tab.cmvn_scale, mel[gi]);
-                }
+                lfr_scatter<OUT_BF16>(fb, t, T, Tp, Tp < p.tp_max ? Tp : p.tp_max, l, p.n_mels, p.lfr_m, p.lfr_n,
+                                      cmvn, mel);
             }
         } else if (t < p.t_max) {
             if constexpr (!FUSED) {
@@ -418,16 +517,25 @@ int32_t launch_fbank(asrfe_ctx* ctx, const FbankParams& p, int pcm_dtype, bool f
     dim3 block(kWavesPerBlock * 64);
     const bool i16 = pcm_dtype == ASRFE_PCM_I16;
     const bool bf = out_dtype == ASRFE_DT_BF16;
-    if (!fused) {
-        if (i16) hipLaunchKernelGGL((fbank_kernel<int16_t, false, false>), grid, block, 0, s, p);
-        else hipLaunchKernelGGL((fbank_kernel<float, false, false>), grid, block, 0, s, p);
-    } else if (bf) {
-        if (i16) hipLaunchKernelGGL((fbank_kernel<int16_t, true, true>), grid, block, 0, s, p);
-        else hipLaunchKernelGGL((fbank_kernel<float, true, true>), grid, block, 0, s, p);
-    } else {
-        if (i16) hipLaunchKernelGGL((fbank_kernel<int16_t, true, false>), grid, block, 0, s, p);
-        else hipLaunchKernelGGL((fbank_kernel<float, true, false>), grid, block, 0, s, p);
-    }
+    bool std_mel = true;
+    for (int g = 0; g < kMelGroups; ++g)
+        std_mel = std_mel && p.tab.mel_gw[g] == 4 * std_mel_chunks(g) && p.tab.mel_go[g] == 4 * std_mel_first(g);
+    auto go = [&](auto pcm_tag, auto fused_tag, auto bf_tag) {
+        using PcmT = decltype(pcm_tag);
+        if (std_mel)
+            hipLaunchKernelGGL((fbank_kernel<PcmT, decltype(fused_tag)::value, decltype(bf_tag)::value, true>), grid, block,
+                               0, s, p);
+        else
+            hipLaunchKernelGGL((fbank_kernel<PcmT, decltype(fused_tag)::value, decltype(bf_tag)::value, false>), grid,
+                               block, 0, s, p);
+    };
+    auto go_pcm = [&](auto fused_tag, auto bf_tag) {
+        if (i16) go(int16_t{}, fused_tag, bf_tag);
+        else go(float{}, fused_tag, bf_tag);
+    };
+    if (!fused) go_pcm(std::false_type{}, std::false_type{});
+    else if (bf) go_pcm(std::true_type{}, std::true_type{});
+    else go_pcm(std::true_type{}, std::false_type{});
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) return set_err(ctx, ASRFE_ERR_HIP, std::string("fbank launch: ") + hipGetErrorString(e));
     return ASRFE_OK;
