@@ -185,12 +185,16 @@ def main():
         prof = eng.ctx.profile_end()
         stages = {k: {"launches_per_step": v[0] // nprof, "ms_per_step": v[1] / nprof} for k, v in prof.items()}
         m = args.batch * TP
+        # QKV projections that run as launches of their own (layer 0 always does); the rest run inside the
+        # post-attention kernel of the layer before
+        n_qkv = stages.get("gemm_qkv", {}).get("launches_per_step", 0)
         flops = {
-            "gemm_qkv": 49 * gemm_flops(m, 1536, 512) + gemm_flops(m, 1536, 560),
+            "gemm_qkv": max(n_qkv - 1, 0) * gemm_flops(m, 1536, 512) + gemm_flops(m, 1536, 560),
             "gemm_out": 50 * gemm_flops(m, 512, 512),
             "gemm_ffn1": 50 * gemm_flops(m, 2048, 512),
             "gemm_ffn2": 50 * gemm_flops(m, 512, 2048),
-            "post_attn": 50 * (gemm_flops(m, 512, 512) + gemm_flops(m, 2048, 512) + gemm_flops(m, 512, 2048)),
+            "post_attn": 50 * (gemm_flops(m, 512, 512) + gemm_flops(m, 2048, 512) + gemm_flops(m, 512, 2048))
+                         + (50 - n_qkv) * gemm_flops(m, 1536, 512),
             "attention": 50 * args.batch * 4 * 2 * gemm_flops(TP, TP, 128),
         }
         for k, f in flops.items():
@@ -201,7 +205,9 @@ def main():
         gemm_ms = sum(stages[k]["ms_per_step"] for k in gemm_kinds)
         gemm_fl = sum(flops[k] for k in gemm_kinds)
         result["gemm_mfma_util"] = gemm_fl / (gemm_ms * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS
-        # the dominant kernel: everything after attention in one launch (Wo + FSMN + residual, norm2, W1, ReLU, W2, next norm1)
+        # the dominant kernel: everything after attention in one launch (Wo + FSMN + residual, norm2, W1, ReLU, W2, next
+        # norm1 and the next layer's QKV projection; the last layer's launch has no projection, so flop_per_launch is
+        # the mean over the 50 launches of a step, as launch_us is)
         dom = "post_attn" if "post_attn" in stages else "gemm_ffn1"
         if dom in stages:
             st = stages[dom]
@@ -209,7 +215,8 @@ def main():
             ach = fl / (st["ms_per_step"] / st["launches_per_step"] * 1e-3) / 1e12
             result["roofline"] = {
                 "kernel": ("post_attn_kernel<f16> (32000 rows per launch: att Wo^T + FSMN + residual, LayerNorm, "
-                           "W1 [2048 x 512], bias + ReLU, W2 [512 x 2048], bias + residual, next LayerNorm)") if dom == "post_attn" else
+                           "W1 [2048 x 512], bias + ReLU, W2 [512 x 2048], bias + residual, next LayerNorm, "
+                           "next layer's Wqkv [1536 x 512] + bias in 49 of 50 launches)") if dom == "post_attn" else
                           "gemm_bf16_kernel<EPI_BF16_RELU> (FFN1: [32000 x 512] x [512 x 2048], bias + ReLU, 16-bit out)",
                 "bound": "mfma",
                 "achieved": ach,

@@ -172,10 +172,12 @@ int32_t asrfe_debug_gemm(asrfe_ctx* ctx, const void* a, int32_t lda, const void*
  * encoder layer `layer` on m rows: att, fsmn [m][512] in the 16-bit compute dtype, x [m][512] float32 or NULL,
  *     x_mid = x + fsmn + att Wo^T + b_o,   x_out = x_mid + W2 relu(W1 norm2(x_mid) + b1) + b2   (x_out may alias x)
  * and, when y is not NULL, y [m][512] = x_out normalised to zero mean / unit variance per row, in the compute
- * dtype (the next norm1's scale and shift are folded into the next layer's QKV weights).  flags != 0 are timing
- * experiments that produce wrong results. */
+ * dtype (the next norm1's scale and shift are folded into the next layer's QKV weights).  When qkv is not NULL
+ * (y must be NULL then, and `layer` must not be the last) the kernel also projects the next layer's
+ * qkv [m][1536] = norm1(x_out) Wqkv^T + b_qkv in the compute dtype, as asrfe_encoder_forward has it do.
+ * flags != 0 are timing experiments that produce wrong results. */
 int32_t asrfe_debug_post_attn(asrfe_ctx* ctx, int32_t layer, const void* att, const void* fsmn, const float* x,
-                              float* x_out, void* y, int32_t m, int32_t flags, void* stream);
+                              float* x_out, void* y, void* qkv, int32_t m, int32_t flags, void* stream);
 
 /* Kernel-level test hook (no counterpart in the reference): one launch of the attention + FSMN kernel of encoder
  * layer `layer` on qkv [batch * tp][1536] (16-bit compute dtype; q | k | v, 4 heads of 128) with lens [batch]:

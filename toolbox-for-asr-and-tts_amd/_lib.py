@@ -100,7 +100,7 @@ SIGNATURES = {
                                      C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32,
                                      C.c_int32, C.c_void_p]),
     "asrfe_debug_post_attn": (C.c_int32, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
-                                          C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
+                                          C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
     "asrfe_debug_attention": (C.c_int32, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p,
                                           C.c_void_p, C.c_int32, C.c_void_p]),
     "asrfe_last_error": (C.c_char_p, [C.c_void_p]),

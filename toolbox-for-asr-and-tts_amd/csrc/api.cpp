@@ -172,6 +172,8 @@ extern "C" int32_t asrfe_create(const asrfe_config* cfg, asrfe_ctx** out) {
     {
         const char* e = std::getenv("ASRFE_UNFUSED_FFN");
         ctx->unfused_ffn = e && e[0] == '1';
+        e = std::getenv("ASRFE_SEPARATE_QKV");
+        ctx->separate_qkv = e && e[0] == '1';
     }
     ctx->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     ctx->after_g = ctx->after_b = ctx->pe_inv = nullptr;
@@ -390,14 +392,17 @@ static void fold_layernorm(const HostTensor* w, const HostTensor* c, const HostT
 // followed by four images of W2[128 nq .. +128][64 j .. +64] (128-byte rows as for Wo).  Inside every group of 16
 // columns of W1 and W2 the k order is p -> swap of bits 2 and 3 of p, the order in which accumulator registers
 // feed the next MFMA; Wo keeps the natural order (its operand is loaded from memory).
+// With wqkv (the NEXT layer's folded [1536][512] projection) twelve more chunks follow, three passes of 512 output
+// rows laid out like Wo but in the swapped k order (their operand is fed from accumulator registers too), and one
+// chunk of zeros that the kernel's last pass prefetches without reading.
 static int32_t up_layer_stream(asrfe_ctx* ctx, const HostTensor* wo, const HostTensor* w1, const HostTensor* w2,
-                               uint16_t** dev) {
+                               const HostTensor* wqkv, uint16_t** dev) {
     const int64_t ff = w1->shape[0], d = w1->shape[1];
     const bool f16 = ctx->cfg.enc_compute_dtype == ASRFE_DT_F16;
     auto cvt = [&](float w) { return f16 ? f16_rne(w) : bf16_rne(w); };
     auto swap23 = [](int64_t c) { return (c & ~int64_t{12}) | ((c & 4) << 1) | ((c & 8) >> 1); };
     const int64_t nch = ff / 64;
-    std::vector<uint16_t> v(static_cast<size_t>((4 + nch) * 8 * 8192), 0);
+    std::vector<uint16_t> v(static_cast<size_t>((4 + nch + (wqkv ? 13 : 0)) * 8 * 8192), 0);
     for (int64_t c = 0; c < 4; ++c)
         for (int64_t r8 = 0; r8 < 8; ++r8) {
             uint16_t* img = v.data() + (8 * c + r8) * 8192;
@@ -427,6 +432,18 @@ static int32_t up_layer_stream(asrfe_ctx* ctx, const HostTensor* wo, const HostT
                     }
         }
     }
+    if (wqkv)
+        for (int64_t c = 0; c < 12; ++c)
+            for (int64_t r8 = 0; r8 < 8; ++r8) {
+                uint16_t* img = v.data() + (8 * (4 + nch + c) + r8) * 8192;
+                const int64_t ks = 2 * (c & 3) + (r8 >> 2), n0 = 512 * (c >> 2) + 128 * (r8 & 3);
+                for (int64_t r = 0; r < 128; ++r)
+                    for (int64_t cs = 0; cs < 8; ++cs)
+                        for (int64_t e = 0; e < 8; ++e) {
+                            const int64_t kp = 64 * ks + 8 * (cs ^ ((r >> 1) & 7)) + e;
+                            img[(r * 8 + cs) * 8 + e] = cvt(wqkv->data[(n0 + r) * d + swap23(kp)]);
+                        }
+            }
     return upload(ctx, v, dev);
 }
 
@@ -448,19 +465,28 @@ extern "C" int32_t asrfe_load_encoder_weights(asrfe_ctx* ctx, const asrfe_tensor
     const int64_t d = c.enc_output_size, ff = c.enc_linear_units, ks = c.enc_kernel_size;
     ctx->layers.assign(c.enc_num_blocks, LayerWeights{});
     int32_t rc;
-    for (int li = 0; li < c.enc_num_blocks; ++li) {
+    // norm1 folded into linear_q_k_v of layer li
+    auto fold_qkv = [&](int li, std::vector<float>& wfold, std::vector<float>& cfold, const HostTensor** w_shape) -> int32_t {
         const std::string p = li == 0 ? std::string("encoders0.0") : "encoders." + std::to_string(li - 1);
         const int64_t din = li == 0 ? c.enc_input_size : d;
+        const HostTensor *tg, *tb, *tw, *tc;
+        int32_t r;
+        if ((r = need(ctx, m, p + ".norm1.weight", {din}, &tg)) || (r = need(ctx, m, p + ".norm1.bias", {din}, &tb)) ||
+            (r = need(ctx, m, p + ".self_attn.linear_q_k_v.weight", {3 * d, din}, &tw)) ||
+            (r = need(ctx, m, p + ".self_attn.linear_q_k_v.bias", {3 * d}, &tc)))
+            return r;
+        fold_layernorm(tw, tc, tg, tb, wfold, cfold);
+        *w_shape = tw;
+        return ASRFE_OK;
+    };
+    for (int li = 0; li < c.enc_num_blocks; ++li) {
+        const std::string p = li == 0 ? std::string("encoders0.0") : "encoders." + std::to_string(li - 1);
         const int kpad = li == 0 ? ctx->kin_pad : static_cast<int>(d);
         LayerWeights& L = ctx->layers[li];
         const HostTensor* t;
         const HostTensor *tg, *tb, *tw, *tc;
         std::vector<float> wfold, cfold;
-        if ((rc = need(ctx, m, p + ".norm1.weight", {din}, &tg)) || (rc = need(ctx, m, p + ".norm1.bias", {din}, &tb)) ||
-            (rc = need(ctx, m, p + ".self_attn.linear_q_k_v.weight", {3 * d, din}, &tw)) ||
-            (rc = need(ctx, m, p + ".self_attn.linear_q_k_v.bias", {3 * d}, &tc)))
-            return rc;
-        fold_layernorm(tw, tc, tg, tb, wfold, cfold);
+        if ((rc = fold_qkv(li, wfold, cfold, &tw))) return rc;
         {
             const HostTensor view{wfold.data(), tw->shape};
             if ((rc = up_bf16(ctx, &view, kpad, &L.w_qkv)) || (rc = upload(ctx, cfold, &L.b_qkv))) return rc;
@@ -485,7 +511,15 @@ extern "C" int32_t asrfe_load_encoder_weights(asrfe_ctx* ctx, const asrfe_tensor
         if ((rc = need(ctx, m, p + ".feed_forward.w_2.weight", {d, ff}, &t)) || (rc = up_bf16(ctx, t, static_cast<int>(ff), &L.w_ffn2))) return rc;
         if (d != 512 || ff % 64 != 0 || ff > 7168)
             return set_err(ctx, ASRFE_ERR_SHAPE, "asrfe_load_encoder_weights: the fused post-attention kernel needs d = 512 and linear_units a multiple of 64 up to 7168");
-        if ((rc = up_layer_stream(ctx, t_wo, &w1view, t, &L.w_stream))) return rc;
+        {
+            // the next layer's projection closes this layer's stream when the kernel has the LDS for it
+            std::vector<float> qfold, qcfold;
+            const HostTensor* qshape = nullptr;
+            L.stream_has_qkv = li + 1 < c.enc_num_blocks && ff <= kPostAttnQkvMaxFf;
+            if (L.stream_has_qkv && (rc = fold_qkv(li + 1, qfold, qcfold, &qshape))) return rc;
+            const HostTensor qview{qfold.data(), {3 * d, d}};
+            if ((rc = up_layer_stream(ctx, t_wo, &w1view, t, L.stream_has_qkv ? &qview : nullptr, &L.w_stream))) return rc;
+        }
         if ((rc = need(ctx, m, p + ".feed_forward.w_2.bias", {d}, &t)) || (rc = up_f32(ctx, t, &L.b_ffn2))) return rc;
     }
     const HostTensor* t;
@@ -588,7 +622,7 @@ extern "C" int32_t asrfe_debug_gemm(asrfe_ctx* ctx, const void* a, int32_t lda, 
 }
 
 extern "C" int32_t asrfe_debug_post_attn(asrfe_ctx* ctx, int32_t layer, const void* att, const void* fsmn, const float* x,
-                                         float* x_out, void* y, int32_t m, int32_t flags, void* stream) {
+                                         float* x_out, void* y, void* qkv, int32_t m, int32_t flags, void* stream) {
     if (!ctx || !att || !fsmn || !x_out) return set_err(ctx, ASRFE_ERR_BAD_ARG, "asrfe_debug_post_attn: null argument");
     if (!ctx->enc_loaded) return set_err(ctx, ASRFE_ERR_NOT_LOADED, "asrfe_debug_post_attn: encoder weights not loaded");
     if (layer < 0 || layer >= ctx->cfg.enc_num_blocks) return set_err(ctx, ASRFE_ERR_BAD_ARG, "asrfe_debug_post_attn: no such layer");
@@ -598,6 +632,10 @@ extern "C" int32_t asrfe_debug_post_attn(asrfe_ctx* ctx, int32_t layer, const vo
     f.x = x; f.x_out = x_out;
     f.wstream = L.w_stream; f.bo = L.b_out; f.b1 = L.b_ffn1; f.b2 = L.b_ffn2;
     f.y = y; f.ldy = 512;
+    if (qkv) {
+        if (!L.stream_has_qkv) return set_err(ctx, ASRFE_ERR_BAD_ARG, "asrfe_debug_post_attn: this layer's stream has no QKV weights");
+        f.qkv = qkv; f.ldq = 1536; f.bqkv = ctx->layers[layer + 1].b_qkv;
+    }
     f.eps = ctx->cfg.enc_ln_eps; f.M = m; f.ff = ctx->cfg.enc_linear_units; f.flags = flags;
     return launch_post_attn(ctx, f, static_cast<hipStream_t>(stream));
 }

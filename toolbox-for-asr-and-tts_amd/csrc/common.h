@@ -63,8 +63,10 @@ struct LayerWeights {
     uint16_t* w_ffn1; float* b_ffn1;   // bf16 [2048][512]
     uint16_t* w_ffn2; float* b_ffn2;   // bf16 [512][2048]
     // w_out, w_ffn1 and w_ffn2 again as the stream of 16 KiB LDS images the fused post-attention kernel
-    // consumes, in the order it consumes them (layout: post_attn.hip)
+    // consumes, in the order it consumes them (layout: post_attn.hip); with stream_has_qkv the NEXT layer's w_qkv
+    // follows, so that the kernel can project that layer's q, k, v as well
     uint16_t* w_stream;
+    bool stream_has_qkv;
 };
 
 }  // namespace asrfe
@@ -78,6 +80,7 @@ struct asrfe_ctx {
     int kin_pad;  // layer-0 K padded to a multiple of 128
     int num_cus;  // compute units of the device (persistent kernels launch one workgroup per CU)
     bool unfused_ffn;  // ASRFE_UNFUSED_FFN=1 in the environment: LayerNorm + two GEMM launches instead of the fused kernel
+    bool separate_qkv;  // ASRFE_SEPARATE_QKV=1: every layer launches its own QKV projection
     std::vector<asrfe::LayerWeights> layers;
     float* after_g;
     float* after_b;

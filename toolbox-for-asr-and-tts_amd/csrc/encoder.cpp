@@ -74,6 +74,7 @@ int32_t encoder_forward(asrfe_ctx* ctx, const float* feats, const int32_t* lens,
         if ((rc = launch_pe_table(ctx, ctx->pe_inv, Tp, c.enc_input_size, bf.pe, s))) return rc;
     }
 
+    bool qkv_ready = false;  // the previous layer's post-attention kernel already projected this layer's q, k, v
     for (int li = 0; li < c.enc_num_blocks; ++li) {
         const LayerWeights& L = ctx->layers[li];
         const int kin = li == 0 ? ctx->kin_pad : 512;
@@ -83,17 +84,20 @@ int32_t encoder_forward(asrfe_ctx* ctx, const float* feats, const int32_t* lens,
             ProfScope ps(ctx, PK_LN, s);
             rc = launch_ln_input(ctx, feats, bf.pe, std::sqrt(static_cast<float>(c.enc_output_size)), nullptr, nullptr,
                                  c.enc_ln_eps, M, Tp, c.enc_input_size, bf.h, kin, s);
-        } else if (ctx->unfused_ffn) {
+        } else if (ctx->unfused_ffn) {  // (the fused kernel of the previous layer left h or q, k, v)
             ProfScope ps(ctx, PK_LN, s);
             rc = launch_ln512(ctx, bf.x, nullptr, nullptr, c.enc_ln_eps, M, bf.h, s);
         }
         if (rc) return rc;
 
         GemmParams g{};
-        g.A = bf.h; g.lda = kin; g.W = L.w_qkv; g.ldw = kin; g.bias = L.b_qkv;
-        g.M = M; g.N = 1536; g.K = kin; g.out = bf.qkv; g.ldo = 1536;
-        { ProfScope ps(ctx, PK_GEMM_QKV, s); rc = launch_gemm(ctx, g, EPI_BF16, s); }
-        if (rc) return rc;
+        if (!qkv_ready) {
+            g.A = bf.h; g.lda = kin; g.W = L.w_qkv; g.ldw = kin; g.bias = L.b_qkv;
+            g.M = M; g.N = 1536; g.K = kin; g.out = bf.qkv; g.ldo = 1536;
+            { ProfScope ps(ctx, PK_GEMM_QKV, s); rc = launch_gemm(ctx, g, EPI_BF16, s); }
+            if (rc) return rc;
+        }
+        qkv_ready = false;
 
         AttnParams a{};
         a.qkv = bf.qkv; a.ld_qkv = 1536; a.lens = lens; a.out = bf.att; a.ld_out = 512;
@@ -104,13 +108,19 @@ int32_t encoder_forward(asrfe_ctx* ctx, const float* feats, const int32_t* lens,
         if (rc) return rc;
 
         if (!ctx->unfused_ffn) {
-            // output projection + FSMN + residual, feed-forward, and h = the next layer's normalised input: one kernel
+            // output projection + FSMN + residual, feed-forward, and the next layer's q, k, v (or, when the weight
+            // stream does not carry Wqkv, h = the next layer's normalised input): one kernel
             const bool has_next = li + 1 < c.enc_num_blocks;
+            const bool with_qkv = has_next && L.stream_has_qkv && !ctx->separate_qkv;
             FfnParams f{};
             f.att = bf.att; f.fsmn = bf.fsmn;
             f.x = li == 0 ? nullptr : bf.x; f.x_out = bf.x;
             f.wstream = L.w_stream; f.bo = L.b_out; f.b1 = L.b_ffn1; f.b2 = L.b_ffn2;
-            f.y = has_next ? bf.h : nullptr; f.ldy = 512;
+            f.y = has_next && !with_qkv ? bf.h : nullptr; f.ldy = 512;
+            if (with_qkv) {
+                f.bqkv = ctx->layers[li + 1].b_qkv; f.qkv = bf.qkv; f.ldq = 1536;
+                qkv_ready = true;
+            }
             f.eps = c.enc_ln_eps; f.M = M; f.ff = ff;
             { ProfScope ps(ctx, PK_FFN_FUSED, s); rc = launch_post_attn(ctx, f, s); }
             if (rc) return rc;

@@ -39,7 +39,9 @@ int32_t launch_ln_final(asrfe_ctx* ctx, const float* x, const float* g, const fl
 // Everything after the attention kernel in one launch (post_attn.hip):
 //     x_mid = x + fsmn + att Wo^T + b_o,   x_out = x_mid + W2 relu(W1 n(x_mid) + b1) + b2,   y = n(x_out) as 16-bit
 // where n(.) normalises a row to zero mean and unit variance (the LayerNorm scale and shift live in the weights).
-// x may be null (layer 0: no residual into the attention block); x_out may alias x.
+// x may be null (layer 0: no residual into the attention block); x_out may alias x.  With qkv set (and y null) the
+// kernel goes on to the next layer's projection, qkv = n(x_out) Wqkv^T + b_qkv, whose weights close the stream.
+constexpr int kPostAttnQkvMaxFf = 5632;  // linear_units up to which the QKV output fits the LDS budget
 struct FfnParams {
     const uint16_t* att;   // [M][512] attention output, 16-bit
     const uint16_t* fsmn;  // [M][512] FSMN memory, 16-bit
@@ -51,6 +53,9 @@ struct FfnParams {
     const float* b2;       // [512]
     void* y;               // optional 16-bit [M][ldy] in the compute dtype
     int ldy;
+    const float* bqkv;     // [1536] folded bias of the next layer's QKV projection (with qkv)
+    void* qkv;             // optional 16-bit [M][ldq]: q | k | v of the next layer
+    int ldq;
     float eps;
     int M, ff;
     int flags;             // timing experiments only (results are wrong): bit 0 skips the stores

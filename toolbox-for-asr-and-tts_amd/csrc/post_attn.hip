@@ -2,7 +2,9 @@
 //
 //     x_mid = x + fsmn + att Wo^T + b_o                   (attention output projection + FSMN memory + residual)
 //     x_out = x_mid + W2 relu(W1 n(x_mid) + b1) + b2      (position-wise feed-forward, fp32 residual stream)
-//     y     = n(x_out)  as 16-bit                          (optional: the next layer's normalised input)
+//     y     = n(x_out)  as 16-bit                          (OUT 1: the next layer's normalised input), or
+//     qkv   = n(x_out) Wqkv^T + b_qkv  as 16-bit           (OUT 2: the next layer's q, k, v, so that layer needs no
+//                                                           projection launch and y never exists in memory)
 // n(.) normalises a row of 512 to zero mean and unit variance; the scale and shift of the two LayerNorms are
 // folded into W1 / b1 and into the next layer's QKV projection when the weights are loaded.
 //
@@ -25,7 +27,9 @@
 // product exact again without moving any data on the device.
 //
 // Weights stream through LDS as 16 KiB pieces, 8 per chunk; a layer's stream is 4 chunks of Wo followed by one
-// chunk per 64 hidden units:
+// chunk per 64 hidden units and, for OUT 2, by 12 chunks of the next layer's Wqkv (three passes of 512 output
+// columns, each laid out like Wo but with the k order of accumulator-fed operands) and one chunk of padding that
+// the last pass prefetches and nobody reads:
 //     Wo chunk c, piece r : Wo[128 (r & 3) .. +128][64 (2 c + (r >> 2)) .. +64]
 //     FFN pieces 0..3     : W1[chunk rows 64][128 k]   (256-byte rows, 16-byte slot c of row r holds chunk c ^ (r & 15))
 //     FFN pieces 4..7     : W2[128 n][chunk cols 64]
@@ -35,6 +39,7 @@
 // after MFMA i, so in the middle of piece q the wave needs piece q + 1: there it waits (counted vmcnt: five
 // younger pieces stay in flight), meets the other waves at one s_barrier, and then refills the slot of piece
 // q - 1, whose last read every wave finished before that barrier.
+#include <algorithm>
 #include <utility>
 
 #include "common.h"
@@ -52,6 +57,7 @@ constexpr int kFfnThreads = 256;
 constexpr int kFfnRows = 128;
 constexpr int kPieceBytes = 16384;
 constexpr int kFfnRing = 8 * kPieceBytes;  // 128 KiB; the fp32 b1, b2 and b_o vectors follow it
+constexpr int kSlabFloats = 4096;          // four wave-private 4 KiB output slabs
 
 template <int I>
 using IC = std::integral_constant<int, I>;
@@ -150,7 +156,8 @@ __device__ __forceinline__ u16x8 pack8(float a0, float a1, float a2, float a3, f
 }
 
 
-template <bool F16, bool HAS_Y>
+// OUT: 0 = x_out only, 1 = x_out and y, 2 = x_out and the next layer's qkv
+template <bool F16, int OUT>
 __global__ __launch_bounds__(kFfnThreads) void post_attn_kernel(const FfnParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
@@ -159,9 +166,12 @@ __global__ __launch_bounds__(kFfnThreads) void post_attn_kernel(const FfnParams 
     const int l31 = lane & 31, h = lane >> 5;
     const int row0 = blockIdx.x * kFfnRows + wave * 32;
     const int nch = p.ff >> 6;
+    // the bias vectors live in LDS: a global load per use would be waited for one by one.  The b1 area is at least
+    // 16 KiB: after the feed-forward it holds the waves' output slabs (OUT 2).
     float* b1s = reinterpret_cast<float*>(smem + kFfnRing);
-    float* b2s = b1s + p.ff;   // the bias vectors live in LDS: a global load per use would be waited for one by one
+    float* b2s = b1s + max(p.ff, kSlabFloats);
     float* bos = b2s + 512;
+    float* bqs = bos + 512;  // b_qkv of the next layer, 1536 (OUT 2)
 
     // ---- staging: the weights arrive as a stream of ready-made 16 KiB LDS images, so a wave copies four
     //      contiguous 1 KiB runs per piece
@@ -189,6 +199,10 @@ __global__ __launch_bounds__(kFfnThreads) void post_attn_kernel(const FfnParams 
         *reinterpret_cast<float4*>(b1s + i) = *reinterpret_cast<const float4*>(p.b1 + i);
     if (tid < 128) *reinterpret_cast<float4*>(b2s + tid * 4) = *reinterpret_cast<const float4*>(p.b2 + tid * 4);
     else *reinterpret_cast<float4*>(bos + (tid - 128) * 4) = *reinterpret_cast<const float4*>(p.bo + (tid - 128) * 4);
+    if constexpr (OUT == 2) {
+        for (int i = tid * 4; i < 1536; i += kFfnThreads * 4)
+            *reinterpret_cast<float4*>(bqs + i) = *reinterpret_cast<const float4*>(p.bqkv + i);
+    }
     __syncthreads();
 
     // ---- activations.  att, fsmn and x come in by LDS-DMA (no staging registers) as 4 KiB slabs of 32 rows x
@@ -298,34 +312,47 @@ __global__ __launch_bounds__(kFfnThreads) void post_attn_kernel(const FfnParams 
     u16x8 wf[8];     // rolling weight fragments
 
     wait_vm_barrier<24>();  // piece 0 has landed everywhere
-    static_for<8>([&](auto f) { wf[decltype(f)::value] = frag2(IC<0>{}, f); });
 
-    // ---- output projection: the row tile += att Wo^T, 4 chunks of 8 pieces
-    static_for<4>([&](auto cc) {
-        constexpr int C = decltype(cc)::value;
-        const char* cb0 = chunk_base(C);
-        const char* cb1 = chunk_base(C + 1);
-        static_for<8>([&](auto rc) {
-            constexpr int R = decltype(rc)::value;
-            constexpr int ks = 2 * C + (R >> 2), nq = R & 3;
-            static_for<8>([&](auto f) {
-                constexpr int F = decltype(f)::value;
-                mfma_agpr<F16>(oacc[4 * nq + (F & 3)], wf[F], afrag[4 * ks + (F >> 2)]);
-                wf[F] = frag2(rc, IC<F + 8>{});
-            });
-            wait_vm_barrier<20>();
-            static_for<8>([&](auto f) {
-                constexpr int F = decltype(f)::value;
-                mfma_agpr<F16>(oacc[4 * nq + (F & 3)], wf[F], afrag[4 * ks + 2 + (F >> 2)]);
-                if constexpr (C == 3 && R == 7) wf[F] = frag1(IC<0>{}, f);
-                else wf[F] = frag2(IC<((R + 1) & 7)>{}, f);
-                if constexpr ((F & 1) == 0) {
-                    if constexpr (R == 0) stage_quarter(IC<7>{}, cb0, F >> 1);
-                    else stage_quarter(IC<(R + 7) & 7>{}, cb1, F >> 1);
-                }
+    // ---- a projection pass: the row tile += afrag W^T for 512 output columns, 4 chunks of 8 pieces starting at
+    //      chunk c0 of the stream, whose piece 0 every wave has seen land.  TO_W1: W1 pieces (256-byte rows) follow
+    //      the pass and their first fragments are read ahead; otherwise the pass ends with nothing read ahead, which
+    //      leaves the registers to the output code behind it.
+    auto proj_pass = [&](int c0, auto to_w1) {
+        constexpr bool TO_W1 = decltype(to_w1)::value;
+        asm volatile("" : "+v"(rb2), "+v"(sw2));  // see chunk() below
+        static_for<8>([&](auto f) { wf[decltype(f)::value] = frag2(IC<0>{}, f); });
+        static_for<4>([&](auto cc) {
+            constexpr int C = decltype(cc)::value;
+            const char* cb0 = chunk_base(c0 + C);
+            const char* cb1 = chunk_base(c0 + C + 1);
+            static_for<8>([&](auto rc) {
+                constexpr int R = decltype(rc)::value;
+                constexpr int ks = 2 * C + (R >> 2), nq = R & 3;
+                static_for<8>([&](auto f) {
+                    constexpr int F = decltype(f)::value;
+                    mfma_agpr<F16>(oacc[4 * nq + (F & 3)], wf[F], afrag[4 * ks + (F >> 2)]);
+                    wf[F] = frag2(rc, IC<F + 8>{});
+                });
+                wait_vm_barrier<20>();
+                static_for<8>([&](auto f) {
+                    constexpr int F = decltype(f)::value;
+                    mfma_agpr<F16>(oacc[4 * nq + (F & 3)], wf[F], afrag[4 * ks + 2 + (F >> 2)]);
+                    if constexpr (C == 3 && R == 7) {
+                        if constexpr (TO_W1) wf[F] = frag1(IC<0>{}, f);
+                    } else {
+                        wf[F] = frag2(IC<((R + 1) & 7)>{}, f);
+                    }
+                    if constexpr ((F & 1) == 0) {
+                        if constexpr (R == 0) stage_quarter(IC<7>{}, cb0, F >> 1);
+                        else stage_quarter(IC<(R + 7) & 7>{}, cb1, F >> 1);
+                    }
+                });
             });
         });
-    });
+    };
+
+    // ---- output projection: the row tile += att Wo^T
+    proj_pass(0, std::true_type{});
 
     // ---- x_mid is complete: row statistics, n(x_mid) as the operand fragments of W1, and b2 into the row tile.
     //      The compiler does not see inside the asm MFMAs, so the wait states between the last of them and the
@@ -385,10 +412,12 @@ __global__ __launch_bounds__(kFfnThreads) void post_attn_kernel(const FfnParams 
         if constexpr (decltype(rc)::value < 4) return frag1(rc, fc);
         else return frag2(rc, fc);
     };
-    // piece R of hidden chunk j; LAST: j is the final chunk (nothing further to stage)
-    auto step = [&](auto rc, int j, const char* cb0, const char* cb1, auto lastc) {
+    // piece R of hidden chunk j; MODE 1: j is the final chunk of the stream (nothing further to stage), MODE 2: j is
+    // the final hidden chunk and projection pieces (128-byte rows) follow it, MODE 0: another hidden chunk follows
+    auto step = [&](auto rc, int j, const char* cb0, const char* cb1, auto mode) {
         constexpr int R = decltype(rc)::value;
-        constexpr bool LAST = decltype(lastc)::value;
+        constexpr bool LAST = decltype(mode)::value == 1;
+        constexpr bool TO_PROJ = decltype(mode)::value == 2;
         static_for<8>([&](auto f) {
             constexpr int F = decltype(f)::value;
             mma(rc, f);
@@ -398,13 +427,13 @@ __global__ __launch_bounds__(kFfnThreads) void post_attn_kernel(const FfnParams 
         else wait_vm_barrier<(R <= 1 ? 20 : (R <= 6 ? 4 * (6 - R) : 0))>();
         // the hidden-chunk accumulators are idle from the ReLU to the end of the chunk: reload them with the next
         // chunk's bias here, eight MFMAs ahead of their first use
-        if constexpr (R == 7 && !LAST) init_acc1(j + 1);
+        if constexpr (R == 7 && !LAST && !TO_PROJ) init_acc1(j + 1);
         // An LDS-DMA instruction holds the wave's issue for tens of cycles, so the four of a piece are spread
         // over the MFMA gaps of the second half instead of being issued back to back.
         static_for<8>([&](auto f) {
             constexpr int F = decltype(f)::value;
             mma(rc, IC<F + 8>{});
-            if constexpr (!(LAST && R == 7)) wf[F] = frag(IC<((R + 1) & 7)>{}, f);
+            if constexpr (!((LAST || TO_PROJ) && R == 7)) wf[F] = frag(IC<((R + 1) & 7)>{}, f);
             if constexpr ((F & 1) == 0) {
                 if constexpr (R == 0) stage_quarter(IC<7>{}, cb0, F >> 1);
                 else if constexpr (!LAST) stage_quarter(IC<(R + 7) & 7>{}, cb1, F >> 1);
@@ -440,8 +469,100 @@ __global__ __launch_bounds__(kFfnThreads) void post_attn_kernel(const FfnParams 
     };
 
     init_acc1(0);
-    for (int j = 0; j < nch - 1; ++j) chunk(j, std::false_type{});
-    chunk(nch - 1, std::true_type{});
+    for (int j = 0; j < nch - 1; ++j) chunk(j, IC<0>{});
+    chunk(nch - 1, IC<(OUT == 2 ? 2 : 1)>{});
+
+    if constexpr (OUT == 2) {
+        // ---- x_out leaves through the wave's slab in the (now idle) b1 area while the ring keeps filling with
+        //      Wqkv pieces; n(x_out) becomes the operand fragments of the QKV projection and the row tile restarts
+        //      from b_qkv.  The tile is then 512 columns of q, of k and of v in turn.
+        asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");
+        char* es = reinterpret_cast<char*>(b1s) + wave * 4096;
+        const int wr_row = l31 * 128, wr_sw = l31 & 7;
+        const int rd_row = lane >> 3, rd_c = lane & 7;
+        float mean = 0.0f, m2 = 0.0f, rstd;
+#pragma unroll
+        for (int nt = 0; nt < 16; ++nt) {
+            const f32x16 t = tile_out(oacc[nt]);
+            stat_merge_tile(mean, m2, 16 * nt, t);
+        }
+        stat_finish_row(mean, m2, p.eps, rstd);
+        const float shift = -mean * rstd;
+        auto bias_tile = [&](int pass, int nt) {
+            f32x16 t;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const float4 u = *reinterpret_cast<const float4*>(bqs + 512 * pass + 32 * nt + 8 * g + 4 * h);
+                t[4 * g] = u.x; t[4 * g + 1] = u.y; t[4 * g + 2] = u.z; t[4 * g + 3] = u.w;
+            }
+            return t;
+        };
+#pragma unroll
+        for (int nt = 0; nt < 16; ++nt) {
+            const f32x16 t = tile_out(oacc[nt]);
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+                *reinterpret_cast<float4*>(es + wr_row + (((2 * g + h) ^ wr_sw) << 4)) =
+                    make_float4(t[4 * g], t[4 * g + 1], t[4 * g + 2], t[4 * g + 3]);
+            ffn_wave_lds_sync();
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int r = rd_row + 8 * i;
+                const float4 v = *reinterpret_cast<const float4*>(es + r * 128 + ((rd_c ^ (r & 7)) << 4));
+                const int m = row0 + r;
+                if (m < p.M && !no_store) *reinterpret_cast<float4*>(p.x_out + static_cast<int64_t>(m) * 512 + 32 * nt + rd_c * 4) = v;
+            }
+            ffn_wave_lds_sync();
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                float v[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = t[8 * q + e] * rstd + shift;
+                afrag[2 * nt + q] = pack8<F16>(v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7]);
+            }
+            // made here and now: left to sink to its first use, the compiler keeps all sixteen tiles alive instead
+            asm volatile("" : "+v"(afrag[2 * nt]), "+v"(afrag[2 * nt + 1]));
+            tile_in(oacc[nt], bias_tile(0, nt));
+        }
+        uint16_t* qkv = reinterpret_cast<uint16_t*>(p.qkv);
+#pragma unroll 1
+        for (int pass = 0; pass < 3; ++pass) {
+            proj_pass(4 + nch + 4 * pass, std::false_type{});
+            asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");
+            // two tiles make one 128-byte row piece; the slab is read back as whole rows
+#pragma unroll
+            for (int nt = 0; nt < 16; ++nt) {
+                const f32x16 t = tile_out(oacc[nt]);
+                const int ns = nt & 1;
+#pragma unroll
+                for (int gp = 0; gp < 2; ++gp) {
+                    const uint32_t lo0 = pack_elem2<F16>(t[8 * gp], t[8 * gp + 1]), lo1 = pack_elem2<F16>(t[8 * gp + 2], t[8 * gp + 3]);
+                    const uint32_t hi0 = pack_elem2<F16>(t[8 * gp + 4], t[8 * gp + 5]), hi1 = pack_elem2<F16>(t[8 * gp + 6], t[8 * gp + 7]);
+                    auto s0 = __builtin_amdgcn_permlane32_swap(lo0, hi0, false, false);
+                    auto s1 = __builtin_amdgcn_permlane32_swap(lo1, hi1, false, false);
+                    const int ch = ns * 4 + 2 * gp + h;
+                    *reinterpret_cast<uint4*>(es + wr_row + ((ch ^ wr_sw) << 4)) = make_uint4(s0[0], s1[0], s0[1], s1[1]);
+                }
+                if (pass < 2) tile_in(oacc[nt], bias_tile(pass + 1, nt));
+                if (ns == 1) {
+                    ffn_wave_lds_sync();
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int r = rd_row + 8 * i;
+                        const uint4 v = *reinterpret_cast<const uint4*>(es + r * 128 + ((rd_c ^ (r & 7)) << 4));
+                        const int m = row0 + r;
+                        if (m < p.M && !no_store)
+                            *reinterpret_cast<uint4*>(qkv + static_cast<int64_t>(m) * p.ldq + 512 * pass + 32 * (nt - 1) + rd_c * 8) = v;
+                    }
+                    ffn_wave_lds_sync();
+                }
+            }
+        }
+        // the padding chunk is still arriving: the LDS must not be handed to another workgroup before it has landed
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        return;
+    }
+    constexpr bool HAS_Y = OUT == 1;
     __syncthreads();  // every wave is done with the ring: it becomes the epilogue's staging area
     // ---- epilogue: 32-row slabs through a wave-private 4 KiB LDS tile so that global stores move whole
     //      128-byte lines (8 consecutive lanes per row)
@@ -515,26 +636,31 @@ int32_t launch_post_attn(asrfe_ctx* ctx, const FfnParams& p, hipStream_t s) {
         return set_err(ctx, ASRFE_ERR_SHAPE, "post_attn: linear_units must be a multiple of 64 in 64..7168");
     if (!p.att || !p.fsmn || !p.x_out || !p.wstream || !p.bo || !p.b1 || !p.b2 || (p.y && p.ldy % 8 != 0))
         return set_err(ctx, ASRFE_ERR_BAD_ARG, "post_attn: null or misaligned argument");
-    const int lds = kFfnRing + p.ff * 4 + 2 * 512 * 4;
+    if (p.qkv && (p.y || !p.bqkv || p.ldq % 8 != 0 || p.ff > kPostAttnQkvMaxFf))
+        return set_err(ctx, ASRFE_ERR_BAD_ARG, "post_attn: qkv output excludes y, needs b_qkv and linear_units <= 5632");
+    const int out = p.qkv ? 2 : (p.y ? 1 : 0);
+    const int lds = kFfnRing + std::max(p.ff, kSlabFloats) * 4 + 2 * 512 * 4 + (out == 2 ? 1536 * 4 : 0);
     const dim3 grid((p.M + kFfnRows - 1) / kFfnRows), block(kFfnThreads);
     const bool f16 = ctx->cfg.enc_compute_dtype == ASRFE_DT_F16;
-#define POST_ATTN_LAUNCH(F, Y)                                                                                  \
+#define POST_ATTN_LAUNCH(F, O)                                                                                  \
     do {                                                                                                        \
         static bool attr_done = false;                                                                          \
         if (!attr_done) {                                                                                       \
-            if (hipFuncSetAttribute(reinterpret_cast<const void*>(post_attn_kernel<F, Y>),                      \
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(post_attn_kernel<F, O>),                      \
                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)      \
                 return set_err(ctx, ASRFE_ERR_HIP, "post_attn: cannot raise the dynamic LDS limit to 160 KiB"); \
             attr_done = true;                                                                                   \
         }                                                                                                       \
-        hipLaunchKernelGGL((post_attn_kernel<F, Y>), grid, block, lds, s, p);                                   \
+        hipLaunchKernelGGL((post_attn_kernel<F, O>), grid, block, lds, s, p);                                   \
     } while (0)
     if (f16) {
-        if (p.y) POST_ATTN_LAUNCH(true, true);
-        else POST_ATTN_LAUNCH(true, false);
+        if (out == 2) POST_ATTN_LAUNCH(true, 2);
+        else if (out == 1) POST_ATTN_LAUNCH(true, 1);
+        else POST_ATTN_LAUNCH(true, 0);
     } else {
-        if (p.y) POST_ATTN_LAUNCH(false, true);
-        else POST_ATTN_LAUNCH(false, false);
+        if (out == 2) POST_ATTN_LAUNCH(false, 2);
+        else if (out == 1) POST_ATTN_LAUNCH(false, 1);
+        else POST_ATTN_LAUNCH(false, 0);
     }
 #undef POST_ATTN_LAUNCH
     const hipError_t e = hipGetLastError();

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Times and checks the fused post-attention kernel in isolation (through asrfe_debug_post_attn).
 
-    python tools/ffn_bench.py [--check] [--iters 30] [--flags 0 1 2 ...]
+    python tools/post_attn_bench.py [--check] [--qkv] [--iters 30] [--flags 0 1 2 ...]
 """
 import argparse
 import ctypes as C
@@ -23,6 +23,7 @@ def main():
     ap.add_argument("--rows", type=int, default=32000)
     ap.add_argument("--repeat", type=int, default=2)
     ap.add_argument("--flags", type=int, nargs="*", default=[0])
+    ap.add_argument("--qkv", action="store_true", help="time the variant that also projects the next layer's q, k, v")
     args = ap.parse_args()
     enc = pkg.SANMEncoder(num_blocks=2)
     sd = encoder_state_dict(num_blocks=2, seed=3)
@@ -49,7 +50,11 @@ def main():
                 xo = torch.empty_like(x)
                 y = torch.empty(m, 512, device=dev, dtype=torch.float16)
                 ctx.check(lib.asrfe_debug_post_attn(ctx.handle, 0, att.data_ptr(), fsmn.data_ptr(),
-                                                    x.data_ptr() if with_x else None, xo.data_ptr(), y.data_ptr(), m, 0, stream))
+                                                    x.data_ptr() if with_x else None, xo.data_ptr(), y.data_ptr(), None, m, 0, stream))
+                xo2 = torch.empty_like(x)
+                qkv = torch.empty(m, 1536, device=dev, dtype=torch.float16)
+                ctx.check(lib.asrfe_debug_post_attn(ctx.handle, 0, att.data_ptr(), fsmn.data_ptr(),
+                                                    x.data_ptr() if with_x else None, xo2.data_ptr(), None, qkv.data_ptr(), m, 0, stream))
                 xm = att.float() @ g[pfx + "self_attn.linear_out.weight"].half().float().T + g[pfx + "self_attn.linear_out.bias"] + fsmn.float()
                 if with_x:
                     xm = xm + x
@@ -57,18 +62,25 @@ def main():
                 h = torch.relu(h.half().float() @ g[pfx + "feed_forward.w_1.weight"].half().float().T + g[pfx + "feed_forward.w_1.bias"])
                 ref = xm + h.half().float() @ g[pfx + "feed_forward.w_2.weight"].half().float().T + g[pfx + "feed_forward.w_2.bias"]
                 yref = torch.nn.functional.layer_norm(ref, (512,), None, None, 1e-12)  # scale / shift live in the next QKV
+                n1 = torch.nn.functional.layer_norm(ref, (512,), g["encoders.0.norm1.weight"], g["encoders.0.norm1.bias"], 1e-12)
+                qref = n1 @ g["encoders.0.self_attn.linear_q_k_v.weight"].T + g["encoders.0.self_attn.linear_q_k_v.bias"]
                 e1 = (xo - ref).abs().max().item()
                 e2 = (y.float() - yref).abs().max().item()
-                print(f"check m={m} x={'yes' if with_x else 'no '}: x_out err {e1:.3e}, y err {e2:.3e}")
-                assert e1 < 3e-3 and e2 < 1e-2
+                e3 = (qkv.float() - qref).abs().max().item()
+                print(f"check m={m} x={'yes' if with_x else 'no '}: x_out err {e1:.3e}, y err {e2:.3e}, qkv err {e3:.3e}, "
+                      f"x_out of both variants equal: {torch.equal(xo, xo2)}")
+                assert e1 < 3e-3 and e2 < 1e-2 and e3 < 2e-2 and torch.equal(xo, xo2)
     m = args.rows
     x = torch.randn(m, 512, device=dev)
     y = torch.empty(m, 512, device=dev, dtype=torch.float16)
     att, fsmn = tens(m)
 
+    qkv = torch.empty(m, 1536, device=dev, dtype=torch.float16)
+
     def launch(flags):
         ctx.check(lib.asrfe_debug_post_attn(ctx.handle, 0, att.data_ptr(), fsmn.data_ptr(), x.data_ptr(), x.data_ptr(),
-                                            y.data_ptr(), m, flags, stream))
+                                            None if args.qkv else y.data_ptr(), qkv.data_ptr() if args.qkv else None,
+                                            m, flags, stream))
 
     import time
     t0 = time.time()
@@ -110,7 +122,8 @@ def main():
         e1.record()
         torch.cuda.synchronize()
         us = 1e3 * e0.elapsed_time(e1) / args.iters
-        print(f"post_attn M={m} flags={flags}: {us:7.1f} us  {2.0 * m * (2048 * 512 * 2 + 512 * 512) / us / 1e6:7.1f} TFLOP/s")
+        flop = 2.0 * m * (2048 * 512 * 2 + 512 * 512 + (1536 * 512 if args.qkv else 0))
+        print(f"post_attn{'+qkv' if args.qkv else ''} M={m} flags={flags}: {us:7.1f} us  {flop / us / 1e6:7.1f} TFLOP/s")
     ref_gemm()
 
 
