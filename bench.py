@@ -91,6 +91,8 @@ def main():
     ap.add_argument("--no-stages", action="store_true")
     ap.add_argument("--streams", type=int, default=2, help="HIP streams (batch chunks) per GPU")
     ap.add_argument("--graph", type=int, default=0, help="1: replay the step from a captured HIP graph")
+    ap.add_argument("--buckets", type=int, default=4, help="length buckets of the ragged side run (0: skip it)")
+    ap.add_argument("--no-extras", action="store_true", help="skip the ragged and host-copy side runs")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -172,6 +174,54 @@ def main():
             "output_finite": out_ok,
             "achieved_tflops_all": value * ALL_FLOP_PER_UTT / 1e12 / world,
         }
+
+    if rank == 0 and world == 1 and not args.no_extras:
+        # ---- side runs, reported beside the headline number and never part of it --------------------------
+        def timed(fn, n):
+            for _ in range(2):
+                fn()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(n):
+                fn()
+            torch.cuda.synchronize()
+            return (time.perf_counter() - t0) / n
+
+        # (1) the same step with the PCM starting in pinned host memory: one 16-bit copy over PCIe per step
+        pcm_host = pcm.cpu().pin_memory()
+        pcm_in = torch.empty_like(pcm)
+
+        def step_h2d():
+            pcm_in.copy_(pcm_host, non_blocking=True)
+            eng.run(pcm_in, lens)
+
+        t_h2d = timed(step_h2d, args.steps)
+        result["host_copy_inclusive"] = {
+            "utt_per_s": args.batch / t_h2d, "ms_per_step": 1e3 * t_h2d,
+            "note": "PCM copied from pinned host memory on the step's stream every step, not overlapped with compute",
+        }
+        del pcm_host, pcm_in
+        # (2) clips of mixed length, U[5 s, 30 s]: padded to the longest clip against length-bucketed.  A bucket
+        #     must still fill the GPU (one 128-row workgroup per CU), so this run uses 4 x the headline batch.
+        if args.buckets > 0:
+            rb = 4 * args.batch
+            eng_r = pkg.AsrEngine(batch=rb, max_samples=SAMPLES, state_dict=sd, n_streams=args.streams,
+                                  n_buckets=args.buckets)
+            pcm_r = torch.from_numpy(bench_pcm(rb, SAMPLES, seed=77)).to(dev)
+            rng = np.random.default_rng(4242)
+            host_lens = rng.integers(5 * 16000, SAMPLES + 1, size=rb).tolist()
+            lens_r = torch.tensor(host_lens, dtype=torch.int32, device=dev)
+            n = max(2, args.steps // 2)
+            t_pad = timed(lambda: eng_r.run(pcm_r, lens_r), n)
+            t_bkt = timed(lambda: eng_r.run_ragged(pcm_r, lens_r, host_lens), n)
+            audio_s = sum(host_lens) / 16000.0
+            result["ragged"] = {
+                "clips": rb, "lens": "U[5 s, 30 s], numpy default_rng(4242)", "mean_clip_s": audio_s / rb,
+                "padded_utt_per_s": rb / t_pad, "bucketed_utt_per_s": rb / t_bkt,
+                "padded_audio_s_per_s": audio_s / t_pad, "bucketed_audio_s_per_s": audio_s / t_bkt,
+                "buckets": args.buckets,
+            }
+            del eng_r, pcm_r
 
     if rank == 0 and not args.no_stages:
         # ---- per-kernel HIP-event pass (same process, same inputs, after the timed region) ----------

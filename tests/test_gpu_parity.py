@@ -422,6 +422,39 @@ def test_engine_streams_give_identical_results(pkg):
     assert torch.equal(out0, out2)
 
 
+def test_engine_ragged_buckets_match_the_padded_step(pkg):
+    """run_ragged (clips ordered by length, every bucket at its own frame count) returns, clip for clip, what the
+    padded fixed-shape step returns: frame counts exactly, encoder rows to 1e-5 (the attention kernel walks a
+    different number of key tiles, everything else is row-wise)."""
+    n = 16000 * 4
+    kinds = ["bursts", "gauss", "chirp", "uniform", "bench", "gauss", "chirp"]
+    clips = np.stack([fo.synth_pcm(k, n, 60 + i) for i, k in enumerate(kinds)])
+    host_lens = [64000, 50000, 16000, 700, 33333, 399, 64000]
+    lens = dev(np.array(host_lens, np.int32))
+    sd = so.make_state_dict(so.SanmConfig(num_blocks=2), seed=3)
+    cfg = pkg.default_config()
+    cfg.enc_num_blocks = 2
+    eng = pkg.AsrEngine(batch=7, max_samples=n, cfg=cfg, state_dict=sd, n_streams=2, n_buckets=3)
+    ref, ref_lens = eng.run(dev(clips), lens)
+    ref, ref_lens = ref.clone(), ref_lens.clone()
+    order, parts = eng.run_ragged(dev(clips), lens, host_lens)
+    torch.cuda.synchronize()
+    assert sorted(order) == list(range(7))
+    assert [host_lens[i] for i in order] == sorted(host_lens)
+    seen = 0
+    for lo, hi, out, out_lens in parts:
+        assert out.shape[0] == hi - lo and out.shape[2] == 512
+        assert out.shape[1] == max(1, max(int(ref_lens[order[j]]) for j in range(lo, hi)))
+        for j in range(lo, hi):
+            u = order[j]
+            t = int(ref_lens[u])
+            assert int(out_lens[j - lo]) == t
+            assert float((out[j - lo, :t] - ref[u, :t]).abs().max()) <= 1e-5 if t else True
+            assert float(out[j - lo, t:].abs().max()) == 0.0 if t < out.shape[1] else True
+            seen += 1
+    assert seen == 7
+
+
 def test_attention_fsmn_kernel_vs_fp64(pkg):
     """The attention + FSMN kernel on its own (debug hook) against an fp64 evaluation of the same 16-bit inputs:
     ragged lengths, a length below the FSMN half-width, T' around the 64-key and 128-query tile edges."""

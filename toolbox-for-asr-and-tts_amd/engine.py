@@ -7,6 +7,10 @@ segments by length, groups them into batches and runs frontend + encoder per bat
 is one such batch slot with every buffer allocated up front, so ``run`` only enqueues kernels on the
 current stream (no allocation, no host synchronisation).
 
+``run_ragged`` is the same step for clips of very different lengths: like the pipeline it orders the clips by
+length and cuts the order into buckets, and every bucket runs at its own longest clip's frame count instead of
+the batch's, so short clips are not padded to the longest one in the batch.
+
 Multi-GPU: utterances are independent, so a batch is split into contiguous ranges, one process and one
 engine per GPU (``shard_range``); nothing is exchanged between ranks.
 """
@@ -36,7 +40,8 @@ class AsrEngine:
     another's MFMA phases), which a single in-order stream cannot do.  Results are identical to n_streams = 1."""
 
     def __init__(self, batch: int, max_samples: int, cfg: _lib.Config | None = None, device=None,
-                 out_dtype=torch.float32, cmvn: tuple | None = None, state_dict=None, n_streams: int = 1):
+                 out_dtype=torch.float32, cmvn: tuple | None = None, state_dict=None, n_streams: int = 1,
+                 n_buckets: int = 0):
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
         with torch.cuda.device(self.device):
             self.ctx = _lib.Context(cfg)
@@ -68,6 +73,17 @@ class AsrEngine:
         with torch.cuda.device(dev):
             self._streams = [torch.cuda.Stream(device=dev) for _ in range(n_streams)] if n_streams > 1 else [None]
             self._done = [torch.cuda.Event() for _ in range(n_streams)]
+        # length buckets of run_ragged (0: that entry point is not used and nothing is allocated for it)
+        n_buckets = max(0, min(int(n_buckets), batch))
+        self.buckets = [shard_range(batch, i, n_buckets) for i in range(n_buckets)]
+        self._bucket_ws = []
+        for lo, hi in self.buckets:
+            nbytes = self.encoder.workspace_bytes(hi - lo, self.tp_max)
+            buf = torch.empty((nbytes + 256,), dtype=torch.uint8, device=dev)
+            self._bucket_ws.append((buf, (buf.data_ptr() + 255) // 256 * 256, nbytes))
+        self._pcm_sorted = None  # [batch, max_samples] in the PCM dtype of the first ragged call
+        self._lens_sorted = torch.zeros((batch,), dtype=torch.int32, device=dev) if n_buckets else None
+        self._order_dev = torch.zeros((batch,), dtype=torch.int64, device=dev) if n_buckets else None
 
     def _check_pcm(self, pcm: torch.Tensor, pcm_lens: torch.Tensor):
         if pcm.device != self.device or pcm_lens.device != self.device or pcm_lens.dtype != torch.int32:
@@ -130,6 +146,64 @@ class AsrEngine:
             self.ctx.handle, self.feats.data_ptr(), self.feat_lens.data_ptr(), self.batch, self.tp_max,
             self.out.data_ptr(), self.out_dtype, ptr, nbytes, st))
         return self.out, self.feat_lens
+
+    def run_ragged(self, pcm: torch.Tensor, pcm_lens: torch.Tensor, host_lens):
+        """The step for clips of mixed lengths.  ``host_lens`` are the sample counts as the host knows them (the same
+        numbers as ``pcm_lens``; reading them back from the device would stall the stream).  Clips are ordered by
+        length (stable) and the order is cut into the engine's ``n_buckets`` ranges; bucket i is computed densely at
+        its own frame count T'_i.  Returns ``(order, parts)``: ``order[j]`` is the index in ``pcm`` of the j-th clip
+        of the ordering, ``parts[i] = (lo, hi, out, out_lens)`` with ``out`` a ``[hi - lo, T'_i, 512]`` view of the
+        engine's output buffer for clips ``order[lo:hi]``.  Only device-to-device copies and kernel launches are
+        enqueued; the sorted PCM staging buffer is allocated on the first call."""
+        if not self.buckets:
+            raise ValueError("AsrEngine.run_ragged: the engine was built with n_buckets = 0")
+        dt = self._check_pcm(pcm, pcm_lens)
+        hl = [int(v) for v in host_lens]
+        if len(hl) != self.batch or (hl and (min(hl) < 0 or max(hl) > pcm.shape[1])):
+            raise ValueError("AsrEngine.run_ragged: host_lens must hold one in-range sample count per clip")
+        order = sorted(range(self.batch), key=lambda i: hl[i])
+        if self._pcm_sorted is None or self._pcm_sorted.dtype != pcm.dtype:
+            self._pcm_sorted = torch.zeros((self.batch, self.max_samples), dtype=pcm.dtype, device=self.device)
+        ps = self._pcm_sorted
+        self._order_dev.copy_(torch.tensor(order, dtype=torch.int64), non_blocking=True)
+        if pcm.shape[1] == self.max_samples:
+            torch.index_select(pcm, 0, self._order_dev, out=ps)
+        else:  # narrower input: the gather goes through a temporary
+            ps[:, :pcm.shape[1]].copy_(pcm.index_select(0, self._order_dev))
+        torch.index_select(pcm_lens, 0, self._order_dev, out=self._lens_sorted)
+        cur = torch.cuda.current_stream(self.device)
+        c = self.ctx.cfg
+        feat_dim, out_dim = c.lfr_m * c.n_mels, c.enc_output_size
+        parts = []
+        used = set()
+        for i, (lo, hi) in enumerate(self.buckets):
+            n = hi - lo
+            tp = max(1, self.frontend.num_lfr_frames(self.frontend.num_frames(max(hl[j] for j in order[lo:hi]))))
+            k = i % len(self._streams)
+            s = self._streams[k]
+            if s is None:
+                st = C.c_void_p(cur.cuda_stream)
+            else:
+                if k not in used:
+                    s.wait_stream(cur)
+                st = C.c_void_p(s.cuda_stream)
+            used.add(k)
+            feats = self.feats[lo:hi]
+            self.ctx.check(self.ctx.lib.asrfe_frontend(
+                self.ctx.handle, ps.data_ptr() + lo * ps.stride(0) * ps.element_size(), dt, ps.stride(0),
+                self._lens_sorted.data_ptr() + 4 * lo, n, tp, feats.data_ptr(), _lib.DT_F32,
+                self.feat_lens.data_ptr() + 4 * lo, st))
+            _, ptr, nbytes = self._bucket_ws[i]
+            self.ctx.check(self.ctx.lib.asrfe_encoder_forward(
+                self.ctx.handle, feats.data_ptr(), self.feat_lens.data_ptr() + 4 * lo, n, tp,
+                self.out[lo:hi].data_ptr(), self.out_dtype, ptr, nbytes, st))
+            out = self.out[lo:hi].reshape(-1)[: n * tp * out_dim].view(n, tp, out_dim)
+            parts.append((lo, hi, out, self.feat_lens[lo:hi]))
+        for k in used:
+            if self._streams[k] is not None:
+                self._done[k].record(self._streams[k])
+                cur.wait_event(self._done[k])
+        return order, parts
 
     def run_frontend(self, pcm: torch.Tensor, pcm_lens: torch.Tensor):
         """pcm [batch, >= max len] int16/float32 and pcm_lens [batch] int32, both on this device."""
