@@ -187,8 +187,10 @@ def main():
             torch.cuda.synchronize()
             return (time.perf_counter() - t0) / n
 
-        # (1) the same step with the PCM starting in pinned host memory: one 16-bit copy over PCIe per step
+        # (1) the same step with the PCM starting in pinned host memory: one 16-bit copy over PCIe per step, first
+        #     in line with the step, then staged one batch ahead on a copy stream (AsrEngine.stage / run_staged)
         pcm_host = pcm.cpu().pin_memory()
+        lens_host = lens.cpu().pin_memory()
         pcm_in = torch.empty_like(pcm)
 
         def step_h2d():
@@ -196,9 +198,19 @@ def main():
             eng.run(pcm_in, lens)
 
         t_h2d = timed(step_h2d, args.steps)
+        slot = [0]
+        eng.stage(pcm_host, lens_host, 0)
+
+        def step_staged():
+            eng.stage(pcm_host, lens_host, slot[0] ^ 1)
+            eng.run_staged(slot[0])
+            slot[0] ^= 1
+
+        t_staged = timed(step_staged, args.steps)
         result["host_copy_inclusive"] = {
-            "utt_per_s": args.batch / t_h2d, "ms_per_step": 1e3 * t_h2d,
-            "note": "PCM copied from pinned host memory on the step's stream every step, not overlapped with compute",
+            "in_line": {"utt_per_s": args.batch / t_h2d, "ms_per_step": 1e3 * t_h2d},
+            "staged_one_batch_ahead": {"utt_per_s": args.batch / t_staged, "ms_per_step": 1e3 * t_staged},
+            "note": "int16 PCM copied from pinned host memory every step",
         }
         del pcm_host, pcm_in
         # (2) clips of mixed length, U[5 s, 30 s]: padded to the longest clip against length-bucketed.  A bucket

@@ -422,6 +422,33 @@ def test_engine_streams_give_identical_results(pkg):
     assert torch.equal(out0, out2)
 
 
+def test_engine_staged_host_batches_match_direct_runs(pkg):
+    """Batches staged from pinned host memory one ahead of the step (two device slots, a copy stream) give exactly
+    what run() gives on device-resident copies of the same batches."""
+    n = 16000 * 2
+    sd = so.make_state_dict(so.SanmConfig(num_blocks=1), seed=3)
+    cfg = pkg.default_config()
+    cfg.enc_num_blocks = 1
+    eng = pkg.AsrEngine(batch=3, max_samples=n, cfg=cfg, state_dict=sd, n_streams=2)
+    batches = []
+    for b in range(3):
+        clips = np.stack([fo.synth_pcm(k, n, 10 * b + i) for i, k in enumerate(["gauss", "chirp", "bursts"])])
+        lens = np.array([n, n - 1234 * (b + 1), 5000 + 700 * b], np.int32)
+        batches.append((torch.from_numpy(clips).pin_memory(), torch.from_numpy(lens).pin_memory()))
+    want = []
+    for clips, lens in batches:
+        out, ol = eng.run(clips.cuda(), lens.cuda())
+        want.append((out.clone(), ol.clone()))
+    eng.stage(*batches[0], 0)
+    for b in range(3):
+        if b + 1 < 3:
+            eng.stage(*batches[b + 1], (b + 1) & 1)
+        out, ol = eng.run_staged(b & 1)
+        torch.cuda.synchronize()
+        assert torch.equal(ol, want[b][1])
+        assert torch.equal(out, want[b][0])
+
+
 def test_engine_ragged_buckets_match_the_padded_step(pkg):
     """run_ragged (clips ordered by length, every bucket at its own frame count) returns, clip for clip, what the
     padded fixed-shape step returns: frame counts exactly, encoder rows to 1e-5 (the attention kernel walks a

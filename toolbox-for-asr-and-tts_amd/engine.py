@@ -205,6 +205,37 @@ class AsrEngine:
                 cur.wait_event(self._done[k])
         return order, parts
 
+    def stage(self, pcm_host: torch.Tensor, lens_host: torch.Tensor, slot: int):
+        """Starts the copy of a batch from pinned host memory into device slot 0 or 1 on the engine's copy stream
+        and returns at once; ``run_staged(slot)`` runs the step on it.  Staging batch i + 1 before running batch i
+        hides the PCIe transfer behind the compute of the batch in flight.  The two slots are allocated on first use."""
+        if slot not in (0, 1):
+            raise ValueError("AsrEngine.stage: slot must be 0 or 1")
+        if pcm_host.dim() != 2 or pcm_host.shape[0] != self.batch or pcm_host.shape[1] > self.max_samples:
+            raise ValueError("AsrEngine.stage: pcm_host must be [batch, n <= max_samples]")
+        if not hasattr(self, "_slots") or self._slots[0][0].dtype != pcm_host.dtype:
+            with torch.cuda.device(self.device):
+                self._copy_stream = torch.cuda.Stream(device=self.device)
+                self._slots = [(torch.zeros((self.batch, self.max_samples), dtype=pcm_host.dtype, device=self.device),
+                                torch.zeros((self.batch,), dtype=torch.int32, device=self.device),
+                                torch.cuda.Event(), torch.cuda.Event()) for _ in range(2)]
+        pcm_dev, lens_dev, copied, consumed = self._slots[slot]
+        cs = self._copy_stream
+        cs.wait_event(consumed)  # the step that last read this slot has finished with it
+        with torch.cuda.stream(cs):
+            pcm_dev[:, :pcm_host.shape[1]].copy_(pcm_host, non_blocking=True)
+            lens_dev.copy_(lens_host.to(torch.int32), non_blocking=True)
+            copied.record(cs)
+
+    def run_staged(self, slot: int):
+        """The step on the batch ``stage`` put into ``slot``; same return value as ``run``."""
+        pcm_dev, lens_dev, copied, consumed = self._slots[slot]
+        cur = torch.cuda.current_stream(self.device)
+        cur.wait_event(copied)
+        res = self.run(pcm_dev, lens_dev)
+        consumed.record(cur)
+        return res
+
     def run_frontend(self, pcm: torch.Tensor, pcm_lens: torch.Tensor):
         """pcm [batch, >= max len] int16/float32 and pcm_lens [batch] int32, both on this device."""
         self._run(pcm, pcm_lens, True, False)
