@@ -2,7 +2,7 @@
 //
 //   One workgroup = 4 waves = 128 query rows of one (utterance, head).
 //
-//   FSMN first: fsmn[t][c] = mask_t (v_m[t][c] + sum_j w[j][c] v_m[t + j - 5][c]) for the workgroup's 128 rows and
+//   FSMN: fsmn[t][c] = mask_t (v_m[t][c] + sum_j w[j][c] v_m[t + j - 5][c]) for the workgroup's 128 rows and
 //   its head's 128 channels (v_m = v inside the utterance, else 0).  The 128 + 2 x 5 rows of V it needs are
 //   brought into LDS by LDS-DMA; a thread owns a pair of channels and 32 consecutive rows and slides an 11-tap
 //   window through registers, so a wave stores whole 256-byte rows.
@@ -94,13 +94,16 @@ __global__ __launch_bounds__(kAttnThreads, 2) void attn_kernel(const AttnParams 
 
     // ---- FSMN memory block for rows qb .. qb + 127 of this head -----------------------------------------------
     // timing experiments (a build with -DASRFE_ATTN_TIMING; results are wrong when a bit is set):
-    // 1 no FSMN phase, 2 no PV product, 4 no QK product, 8 no K / V prefetch
+    // 1 no FSMN phase, 2 no PV product, 4 no QK product, 8 no K / V prefetch, 16 no workgroup barrier per tile,
+    // 32 no wait for the tile's loads, 64 no exponentials
 #ifdef ASRFE_ATTN_TIMING
     const int xf = p.flags;
 #else
     constexpr int xf = 0;
 #endif
-    if (!(xf & 1)) {
+    // (runs after the attention proper: measured slightly faster than in front of it, where it delays the first
+    // K / V tile of every workgroup at the same moment)
+    auto fsmn_phase = [&]() {
         // stage row rr (0..143) = V row qb - 5 + rr, clamped into the utterance's rows (masked when used)
         const uint32_t fst = __builtin_amdgcn_readfirstlane(smem_base + kFsmnStage + wave * 1024);
 #pragma unroll
@@ -147,8 +150,8 @@ __global__ __launch_bounds__(kAttnThreads, 2) void attn_kernel(const AttnParams 
             for (int j = 0; j < kFsmnTaps; ++j) acc = __builtin_elementwise_fma(wt[j], xw[(i + j) % kFsmnTaps], acc);
             if (t < p.Tp) out[static_cast<int64_t>(i) * 256] = t < len ? pack_elem2<F16>(acc.x, acc.y) : 0u;
         }
-        __syncthreads();  // the stage is consumed: its bytes become K, V tile 1
-    }
+        __syncthreads();
+    };
 
     // Use the Q fragments once here: the compiler then waits for their loads before the loop.  Left to their first
     // use inside the loop, its vmcnt waits there would also drain the K / V prefetch it does not know about.
@@ -170,6 +173,16 @@ __global__ __launch_bounds__(kAttnThreads, 2) void attn_kernel(const AttnParams 
             }
     }
 
+#ifdef ASRFE_ATTN_TIMING
+    // experiment (flag 512, with flag 1): wave 0 of workgroup 300 writes cycle-counter stamps into the unused fsmn buffer
+    long long* trace = reinterpret_cast<long long*>(p.fsmn);
+    int trace_n = 0;
+    const bool tracing = (xf & 512) && bid == 300 && wave == 0;
+#define ATTN_STAMP() do { if (tracing) { const long long tsc = __builtin_readcyclecounter(); if (lane == 0) trace[trace_n] = tsc; ++trace_n; } } while (0)
+#else
+#define ATTN_STAMP() do {} while (0)
+#endif
+    ATTN_STAMP();
     f32x16 oacc[4];
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt)
@@ -183,27 +196,32 @@ __global__ __launch_bounds__(kAttnThreads, 2) void attn_kernel(const AttnParams 
         // tile kt is complete in LDS (this thread's LDS-DMA loads are drained by hand: they are issued through
         // inline assembly, which keeps the compiler's LDS-read waits counted) and every wave is done with tile
         // kt - 1, whose buffer is refilled below
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
+        if (!(xf & 32)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (!(xf & 16)) __syncthreads();
+        ATTN_STAMP();  // 0: past the barrier
         if (kt + 1 < n_kt && !(xf & 8)) kv_issue(kt + 1, cur ^ 1, true);
+        ATTN_STAMP();  // 1: prefetch issued
         const char* ks = smem + ((xf & 8) ? 0 : cur) * kBufBytes;
         const char* vs = ks + kTileBytes;
 
         // ---- S^T = K Q^T : two 32-key sub-tiles ---------------------------------------------
+        // (consecutive MFMAs alternate between the two accumulators: none waits for the one right before it)
         f32x16 sacc[2];
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
+        for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
             for (int e = 0; e < 16; ++e) sacc[kk][e] = 0.0f;
-            const char* krow = ks + (kk * 32 + l31) * 256;
-            if (!(xf & 4)) {
+        if (!(xf & 4)) {
 #pragma unroll
-            for (int s = 0; s < 8; ++s) {
-                const u16x8 kf = *reinterpret_cast<const u16x8*>(krow + (((2 * s + h) ^ (l31 & 15)) << 4));
-                sacc[kk] = mfma32<F16>(kf, qf[s], sacc[kk]);
-            }
-            }
+            for (int s = 0; s < 8; ++s)
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk) {
+                    const char* krow = ks + (kk * 32 + l31) * 256;
+                    const u16x8 kf = *reinterpret_cast<const u16x8*>(krow + (((2 * s + h) ^ (l31 & 15)) << 4));
+                    sacc[kk] = mfma32<F16>(kf, qf[s], sacc[kk]);
+                }
         }
+        ATTN_STAMP();  // 2: QK issued
         if (kt == n_kt - 1) {  // wave-uniform: mask keys at or past the utterance length
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk)
@@ -222,6 +240,7 @@ __global__ __launch_bounds__(kAttnThreads, 2) void attn_kernel(const AttnParams 
         // The running maximum only has to bound the scores well enough for exp2 to stay in range: it is raised
         // (and the accumulators rescaled) only when the tile's maximum exceeds it by more than 2^8 after scaling,
         // so most tiles skip the rescale.  Every tile holds at least one valid key, so rmax is finite.
+        ATTN_STAMP();  // 3: row maximum known
         const bool grew = rmax * c > m_run * c + 8.0f;  // true on the first tile (m_run = -inf)
         const float m_new = grew ? rmax : m_run;
         const float alpha = grew ? __builtin_amdgcn_exp2f((m_run - m_new) * c) : 1.0f;
@@ -243,15 +262,15 @@ __global__ __launch_bounds__(kAttnThreads, 2) void attn_kernel(const AttnParams 
             for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
-                    const float pv = __builtin_amdgcn_exp2f(sacc[kk][8 * s2 + j] * c - mc);
+                    const float pv = (xf & 64) ? sacc[kk][8 * s2 + j] * c - mc : __builtin_amdgcn_exp2f(sacc[kk][8 * s2 + j] * c - mc);
                     psum += pv;
                     pf[s2][j] = to_elem<F16>(pv);
                 }
             if (!(xf & 2)) {
 #pragma unroll
-                for (int mt = 0; mt < 4; ++mt)
+                for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
-                    for (int s2 = 0; s2 < 2; ++s2) {
+                    for (int mt = 0; mt < 4; ++mt) {
                         // element j of the fragment is key 32 kk + 16 s2 + 8 (j >> 2) + 4 h + (j & 3)
                         const char* blk = vs + (kk * 32 + s2 * 16) * 256;
                         const v4s lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
@@ -264,7 +283,9 @@ __global__ __launch_bounds__(kAttnThreads, 2) void attn_kernel(const AttnParams 
             }
         }
         l_run = l_run * alpha + psum;
+        ATTN_STAMP();  // 4: exponentials and PV issued
     }
+    ATTN_STAMP();
 
     // ---- normalise; each wave routes its 32 x 128 tile through LDS so that 16 lanes store one full 256-byte row ----
     const float l_tot = l_run + __shfl_xor(l_run, 32);
@@ -294,6 +315,7 @@ __global__ __launch_bounds__(kAttnThreads, 2) void attn_kernel(const AttnParams 
         const int qr = q0 + r;
         if (qr < p.Tp) *reinterpret_cast<uint4*>(p.out + (row0 + qr) * p.ld_out + head * 128 + cch * 8) = v;
     }
+    if (!(xf & 1)) fsmn_phase();
 }
 
 int32_t launch_attention(asrfe_ctx* ctx, const AttnParams& p, hipStream_t s) {

@@ -39,6 +39,7 @@ def main():
     ap.add_argument("--iters", type=int, default=30)
     ap.add_argument("--repeat", type=int, default=2)
     ap.add_argument("--flags", type=int, nargs="*", default=[0])
+    ap.add_argument("--len", type=int, default=500, help="valid length of every utterance (T stays 500)")
     args = ap.parse_args()
     enc = pkg.SANMEncoder(num_blocks=1)
     sd = encoder_state_dict(num_blocks=1, seed=3)
@@ -70,7 +71,7 @@ def main():
             assert e1 < 4e-3 and e2 < 8e-3
     B, T = 64, 500
     qkv = (torch.randn(B, T, 1536, device=dev) * 1.5).half()
-    lens = torch.full((B,), T, dtype=torch.int32, device=dev)
+    lens = torch.full((B,), min(T, args.len), dtype=torch.int32, device=dev)
     att = torch.empty(B, T, 512, device=dev, dtype=torch.float16)
     fsmn = torch.empty(B, T, 512, device=dev, dtype=torch.float16)
     t0 = time.time()
@@ -78,6 +79,14 @@ def main():
         for _ in range(50):
             launch(qkv, lens, att, fsmn)
         torch.cuda.synchronize()
+    if any(f & 512 for f in args.flags):
+        fsmn.zero_()
+        launch(qkv, lens, att, fsmn, 513)
+        torch.cuda.synchronize()
+        tr = fsmn.view(-1)[:4 * 64].view(torch.int64).cpu().tolist()
+        tr = [t for t in tr if t]
+        print("trace deltas (cycles):", [b - a for a, b in zip(tr, tr[1:])])
+        return
     for flags in args.flags * args.repeat:
         for _ in range(5):
             launch(qkv, lens, att, fsmn, flags)
