@@ -177,6 +177,38 @@ def test_fbank_full_size_properties(fe):
     assert torch.equal(feats, gathered)
 
 
+@pytest.mark.parametrize("n_mels,lfr_m,lfr_n", [(40, 5, 3), (64, 1, 1), (32, 7, 6)])
+def test_fbank_other_mel_layouts(pkg, n_mels, lfr_m, lfr_n):
+    """Filter counts other than 80 go through the kernel's run-time mel loops (the 80-filter layout has its trip
+    counts compiled in) and other LFR shapes through the scatter: log-mel and features against the oracle."""
+    fe2 = pkg.WavFrontend(n_mels=n_mels, lfr_m=lfr_m, lfr_n=lfr_n)
+    lens = [16000, 5203, 400, 399, 24000]
+    pcm = np.zeros((len(lens), max(lens)), np.int16)
+    for i, n in enumerate(lens):
+        pcm[i, :n] = fo.synth_pcm(["gauss", "chirp", "bursts", "uniform", "bench"][i], n, 40 + i)
+    banks = fo.mel_banks(n_mels=n_mels)
+    got, nfr = fe2.forward_fbank(dev(pcm), lens)
+    feats, flens = fe2.forward(dev(pcm), lens)
+    torch.cuda.synchronize()
+    for i, n in enumerate(lens):
+        want = fo.kaldi_fbank(pcm[i, :n], banks=banks) if n >= 400 else np.zeros((0, n_mels))
+        t = want.shape[0]
+        assert int(nfr[i]) == t
+        if t == 0:
+            assert int(flens[i]) == 0
+            continue
+        assert np.abs(got[i, :t].cpu().numpy() - want).max() <= FBANK_TOL
+        wl = fo.apply_lfr(want, lfr_m, lfr_n)
+        assert int(flens[i]) == wl.shape[0]
+        assert np.abs(feats[i, :wl.shape[0]].cpu().numpy() - wl).max() <= FBANK_TOL
+
+
+def test_too_wide_mel_filters_are_refused(pkg):
+    """23 filters over 20 Hz .. 8 kHz are wider than the kernel's weight table: creation fails with a message."""
+    with pytest.raises(Exception, match="mel filters too wide"):
+        pkg.WavFrontend(n_mels=23)
+
+
 def test_frontend_bf16_output(fe):
     pcm = fo.synth_pcm("gauss", 16000, 9)
     f32, _ = fe.forward(dev(pcm[None]), [16000])
