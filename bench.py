@@ -41,6 +41,17 @@ GEMM_FLOP_PER_UTT = 157.4e9             # QKV + out-proj + FFN over 50 layers at
 ALL_FLOP_PER_UTT = 183.2e9              # + attention matmuls + FSMN
 
 
+def hbm_traffic(kernel):
+    """HBM bytes per launch of a kernel from the newest committed counter pass (profiles/r*_hbm_traffic.json: the
+    counters need rocprofv3 runs of their own, so they cannot be taken inside this process); None if there is none."""
+    import glob
+    files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r*_hbm_traffic.json")))
+    if not files:
+        return None
+    k = json.load(open(files[-1])).get("kernels", {}).get(kernel)
+    return None if k is None else k["fetch_bytes"] + k["write_bytes"]
+
+
 def gemm_flops(m, n, k):
     return 2.0 * m * n * k
 
@@ -285,7 +296,7 @@ def main():
                 "peak": MFMA_BF16_PEAK_TFLOPS,
                 "unit": "TFLOP/s",
                 "frac": ach / MFMA_BF16_PEAK_TFLOPS,
-                "traffic": None,
+                "traffic": hbm_traffic("post_attn") if dom == "post_attn" else None,
                 "launch_us": 1e3 * st["ms_per_step"] / st["launches_per_step"],
                 "flop_per_launch": fl,
             }
