@@ -366,6 +366,24 @@ def test_encoder_nontrivial_layernorm_parameters(pkg):
     assert err <= ENC_TOL, err
 
 
+@pytest.mark.parametrize("ff", [256, 1280, 3072, 5888])
+def test_encoder_other_feed_forward_widths(pkg, ff):
+    """linear_units other than 2048: the weight stream of the post-attention kernel has ff / 64 hidden chunks, and
+    above 5632 units its LDS has no room for the fused QKV projection, so every layer launches its own (5888 takes
+    that plan).  3 layers against the oracle."""
+    cfg = so.SanmConfig(num_blocks=3, linear_units=ff)
+    sd = _trained_like(so.make_state_dict(cfg, seed=20 + ff, dtype=torch.float32), seed=21)
+    lens = torch.tensor([70, 33, 129], dtype=torch.int32)
+    feats = so.synth_feats(3, 129, 560, seed=5)
+    enc = pkg.SANMEncoder(num_blocks=3, linear_units=ff)
+    enc.load_state_dict(sd)
+    out, olens, _ = enc.forward(feats.cuda(), lens)
+    want, wl = so.encoder_forward(feats.double(), lens, {k: v.double() for k, v in sd.items()}, cfg)
+    assert olens.cpu().tolist() == wl.tolist()
+    err = float((out.cpu().double() - want).abs().max())
+    assert err <= ENC_TOL, (ff, err)
+
+
 def test_post_attention_kernel_vs_fp64(pkg):
     """The fused kernel behind attention (output projection + FSMN + residual, norm2, feed-forward, next-layer
     normalisation or next-layer QKV projection) on its own, through the debug hook: x_out within 2e-3, the normalised
