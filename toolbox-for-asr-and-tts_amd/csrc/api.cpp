@@ -632,6 +632,10 @@ extern "C" int32_t asrfe_debug_post_attn(asrfe_ctx* ctx, int32_t layer, const vo
     f.x = x; f.x_out = x_out;
     f.wstream = L.w_stream; f.bo = L.b_out; f.b1 = L.b_ffn1; f.b2 = L.b_ffn2;
     f.y = y; f.ldy = 512;
+    if (qkv && (flags & 256)) {  // timing build: y carries the stamp buffer
+        f.trace = static_cast<long long*>(y);
+        f.y = nullptr;
+    }
     if (qkv) {
         if (!L.stream_has_qkv) return set_err(ctx, ASRFE_ERR_BAD_ARG, "asrfe_debug_post_attn: this layer's stream has no QKV weights");
         f.qkv = qkv; f.ldq = 1536; f.bqkv = ctx->layers[layer + 1].b_qkv;

@@ -59,6 +59,7 @@ struct FfnParams {
     float eps;
     int M, ff;
     int flags;             // timing experiments only (results are wrong): bit 0 skips the stores
+    long long* trace;      // timing build only: cycle-counter stamps of one wave (flags bit 8)
 };
 int32_t launch_post_attn(asrfe_ctx* ctx, const FfnParams& p, hipStream_t s);
 

@@ -173,6 +173,15 @@ __global__ __launch_bounds__(kFfnThreads) void post_attn_kernel(const FfnParams 
     float* bos = b2s + 512;
     float* bqs = bos + 512;  // b_qkv of the next layer, 1536 (OUT 2)
 
+#if ASRFE_FFN_TIMING
+    // timing build, flags bit 8: wave 0 of workgroup 100 writes cycle-counter stamps to p.trace
+    int trace_n = 0;
+    const bool tracing = (p.flags & 256) && p.trace && blockIdx.x == 100 && wave == 0;
+#define FFN_STAMP() do { if (tracing) { const long long tsc = __builtin_readcyclecounter(); if (lane == 0) p.trace[trace_n] = tsc; ++trace_n; } } while (0)
+#else
+#define FFN_STAMP() do {} while (0)
+#endif
+    FFN_STAMP();
     // ---- staging: the weights arrive as a stream of ready-made 16 KiB LDS images, so a wave copies four
     //      contiguous 1 KiB runs per piece
     const char* wsrc = reinterpret_cast<const char*>(p.wstream);
@@ -352,7 +361,9 @@ __global__ __launch_bounds__(kFfnThreads) void post_attn_kernel(const FfnParams 
     };
 
     // ---- output projection: the row tile += att Wo^T
+    FFN_STAMP();  // prologue done
     proj_pass(0, std::true_type{});
+    FFN_STAMP();  // output projection done
 
     // ---- x_mid is complete: row statistics, n(x_mid) as the operand fragments of W1, and b2 into the row tile.
     //      The compiler does not see inside the asm MFMAs, so the wait states between the last of them and the
@@ -469,8 +480,10 @@ __global__ __launch_bounds__(kFfnThreads) void post_attn_kernel(const FfnParams 
     };
 
     init_acc1(0);
+    FFN_STAMP();  // LayerNorm pass done
     for (int j = 0; j < nch - 1; ++j) chunk(j, IC<0>{});
     chunk(nch - 1, IC<(OUT == 2 ? 2 : 1)>{});
+    FFN_STAMP();  // feed-forward done
 
     if constexpr (OUT == 2) {
         // ---- x_out leaves through the wave's slab in the (now idle) b1 area while the ring keeps filling with
@@ -525,9 +538,11 @@ __global__ __launch_bounds__(kFfnThreads) void post_attn_kernel(const FfnParams 
             tile_in(oacc[nt], bias_tile(0, nt));
         }
         uint16_t* qkv = reinterpret_cast<uint16_t*>(p.qkv);
+        FFN_STAMP();  // x_out stored, n(x_out) in fragments
 #pragma unroll 1
         for (int pass = 0; pass < 3; ++pass) {
             proj_pass(4 + nch + 4 * pass, std::false_type{});
+            FFN_STAMP();  // projection pass computed (the pass before it stored)
             asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");
             // two tiles make one 128-byte row piece; the slab is read back as whole rows
 #pragma unroll
@@ -558,6 +573,7 @@ __global__ __launch_bounds__(kFfnThreads) void post_attn_kernel(const FfnParams 
                 }
             }
         }
+        FFN_STAMP();  // q, k, v stored
         // the padding chunk is still arriving: the LDS must not be handed to another workgroup before it has landed
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         return;

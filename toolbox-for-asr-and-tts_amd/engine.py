@@ -219,6 +219,8 @@ class AsrEngine:
                 self._slots = [(torch.zeros((self.batch, self.max_samples), dtype=pcm_host.dtype, device=self.device),
                                 torch.zeros((self.batch,), dtype=torch.int32, device=self.device),
                                 torch.cuda.Event(), torch.cuda.Event()) for _ in range(2)]
+                # the zero fills above run on the current stream: the first copy must not overtake them
+                self._copy_stream.wait_stream(torch.cuda.current_stream(self.device))
         pcm_dev, lens_dev, copied, consumed = self._slots[slot]
         cs = self._copy_stream
         cs.wait_event(consumed)  # the step that last read this slot has finished with it
