@@ -28,6 +28,7 @@ def main():
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--repeat", type=int, default=3)
     ap.add_argument("--batch", type=int, default=256)
+    ap.add_argument("--bench-pcm", action="store_true", help="use bench.py's synthetic PCM (10 % leading zeros per clip)")
     args = ap.parse_args()
     fe = pkg.WavFrontend()
     dev = "cuda"
@@ -57,7 +58,11 @@ def main():
         assert worst < 1e-3 and worst2 < 1e-3
     fb = args.batch
     rng = np.random.default_rng(1)
-    pcm = torch.from_numpy((rng.standard_normal((fb, SAMPLES)) * 3000).astype(np.int16)).to(dev)
+    if args.bench_pcm:
+        from toolbox_for_asr_and_tts_amd.synth import bench_pcm
+        pcm = torch.from_numpy(bench_pcm(fb, SAMPLES, seed=4321)).to(dev)
+    else:
+        pcm = torch.from_numpy((rng.standard_normal((fb, SAMPLES)) * 3000).astype(np.int16)).to(dev)
     lens = torch.full((fb,), SAMPLES, dtype=torch.int32, device=dev)
     T = fe.num_frames(SAMPLES)
     Tp = fe.num_lfr_frames(T)
