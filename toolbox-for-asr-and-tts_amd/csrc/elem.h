@@ -21,14 +21,15 @@ __device__ __forceinline__ uint16_t to_elem(float v) {
 
 template <bool F16>
 __device__ __forceinline__ uint32_t pack_elem2(float a, float b) {
+    // a two-element vector conversion: one v_cvt_pk_{f16,bf16}_f32 (round to nearest even)
+    typedef __attribute__((ext_vector_type(2))) float f2;
+    const f2 ab = {a, b};
     if constexpr (F16) {
         typedef __attribute__((ext_vector_type(2))) _Float16 h2;
-        h2 v = {static_cast<_Float16>(a), static_cast<_Float16>(b)};
-        return __builtin_bit_cast(uint32_t, v);
+        return __builtin_bit_cast(uint32_t, __builtin_convertvector(ab, h2));
     } else {
         typedef __attribute__((ext_vector_type(2))) __bf16 b2;
-        b2 v = {static_cast<__bf16>(a), static_cast<__bf16>(b)};
-        return __builtin_bit_cast(uint32_t, v);
+        return __builtin_bit_cast(uint32_t, __builtin_convertvector(ab, b2));
     }
 }
 

@@ -146,7 +146,11 @@ __device__ __forceinline__ void stat_finish_row(float& mean, float m2, float eps
     rstd = 1.0f / sqrtf(m2 * (1.0f / 512.0f) + eps);
 }
 
-__device__ __forceinline__ float relu(float v) { return __builtin_amdgcn_fmed3f(v, 0.0f, __builtin_inff()); }
+__device__ __forceinline__ u16x8 relu16(const u16x8 v) {
+    typedef short s16x8 __attribute__((ext_vector_type(8)));
+    const s16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+    return __builtin_bit_cast(u16x8, __builtin_elementwise_max(__builtin_bit_cast(s16x8, v), z));
+}
 
 template <bool F16>
 __device__ __forceinline__ u16x8 pack8(float a0, float a1, float a2, float a3, float a4, float a5, float a6, float a7) {
@@ -470,8 +474,10 @@ __global__ __launch_bounds__(kFfnThreads) void post_attn_kernel(const FfnParams 
         for (int kk = 0; kk < 4; ++kk) {
             const f32x16& a = acc1[kk >> 1];
             const int o = 8 * (kk & 1);
-            hp[kk] = pack8<F16>(relu(a[o]), relu(a[o + 1]), relu(a[o + 2]), relu(a[o + 3]), relu(a[o + 4]), relu(a[o + 5]),
-                                relu(a[o + 6]), relu(a[o + 7]));
+            // ReLU after the rounding, on the 16-bit pairs: a negative fp16 / bf16 is a negative int16, so one packed
+            // integer max with 0 clamps two values (and turns -0 into +0); rounding keeps the sign, so the result is
+            // the one of ReLU before rounding
+            hp[kk] = relu16(pack8<F16>(a[o], a[o + 1], a[o + 2], a[o + 3], a[o + 4], a[o + 5], a[o + 6], a[o + 7]));
         }
         step(IC<4>{}, j, cb0, cb1, lastc);
         step(IC<5>{}, j, cb0, cb1, lastc);
