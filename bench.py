@@ -337,7 +337,7 @@ def main():
             "peak": HBM_PEAK_GBPS,
             "unit": "GB/s",
             "frac": gbps / HBM_PEAK_GBPS,
-            "traffic": None,
+            "traffic": hbm_traffic("fbank") if fb == 256 else None,
             "launch_us": us,
             "bytes_per_launch": fb * FBANK_BYTES_PER_UTT,
             "utt_per_s": fb / (us * 1e-6),
