@@ -31,6 +31,8 @@ constexpr int kTileBytes = 64 * 256;       // 64 keys x 128 d, 16-bit
 constexpr int kBufBytes = 2 * kTileBytes;  // K tile | V tile
 constexpr int kFsmnHalo = 5;
 constexpr int kFsmnTaps = 11;
+constexpr int kFsmnTapBytes = kFsmnTaps * 128 * 4;  // the head's taps, f32 [11][128], behind the stage
+constexpr int kFsmnTapOfs = 2 * kBufBytes + 4096;
 constexpr int kFsmnStage = kBufBytes;      // byte offset of the FSMN stage: 9 DMA rounds of 16 rows (128 + 2 x 5 halo, rounded up)
 
 typedef short v4s __attribute__((ext_vector_type(4)));
@@ -40,7 +42,7 @@ template <bool F16>
 __global__ __launch_bounds__(kAttnThreads, 2) void attn_kernel(const AttnParams p) {
     // two K/V buffers: tile kt + 1 is fetched while tile kt is multiplied.  The FSMN phase stages its 144 rows in
     // bytes [32 KiB, 68 KiB), i.e. over buffer 1 plus 4 KiB, so that K and V tile 0 fly into buffer 0 at the same time.
-    __shared__ __attribute__((aligned(16))) char smem[2 * kBufBytes + 4096];
+    __shared__ __attribute__((aligned(16))) char smem[2 * kBufBytes + 4096 + kFsmnTapBytes];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -80,7 +82,10 @@ __global__ __launch_bounds__(kAttnThreads, 2) void attn_kernel(const AttnParams 
             if (with_v) lds_dma16(vbase, ro + v_chunk * 16, dst + kTileBytes + i * 4096);
         }
     };
-    if (n_kt > 0) kv_issue(0, 0, true);
+    // tile kt uses buffer (n_kt - 1 - kt) & 1: the LAST tile always sits in buffer 0, which leaves buffer 1 and the
+    // 4 KiB behind it free for the FSMN stage to arrive while that tile is computed
+    const int buf_par = (n_kt - 1) & 1;
+    if (n_kt > 0) kv_issue(0, buf_par, true);
 
     // Q fragments: lane holds Q[q0 + l31][16 s + 8 h .. +8), s = 0..7
     u16x8 qf[8];
@@ -102,8 +107,8 @@ __global__ __launch_bounds__(kAttnThreads, 2) void attn_kernel(const AttnParams 
     constexpr int xf = 0;
 #endif
     // (runs after the attention proper: measured slightly faster than in front of it, where it delays the first
-    // K / V tile of every workgroup at the same moment)
-    auto fsmn_phase = [&]() {
+    // K / V tile of every workgroup at the same moment; its rows are fetched during the last key tile)
+    auto fsmn_stage_issue = [&]() {
         // stage row rr (0..143) = V row qb - 5 + rr, clamped into the utterance's rows (masked when used)
         const uint32_t fst = __builtin_amdgcn_readfirstlane(smem_base + kFsmnStage + wave * 1024);
 #pragma unroll
@@ -112,16 +117,25 @@ __global__ __launch_bounds__(kAttnThreads, 2) void attn_kernel(const AttnParams 
             t = t < 0 ? 0 : (t > p.Tp - 1 ? p.Tp - 1 : t);
             lds_dma16(vbase, static_cast<uint32_t>(t) * ldb + (tid & 15) * 16, fst + i * 4096);
         }
+        // the taps of the head's 128 channels: 11 rows of 512 bytes = 352 16-byte pieces, piece q = (tap q / 32,
+        // channels 4 (q % 32) .. +3), one per thread and a second one for the first 96 threads
+        const char* wsrc = reinterpret_cast<const char*>(p.w_fsmn + head * 128);
+        const uint32_t tdst = __builtin_amdgcn_readfirstlane(smem_base + kFsmnTapOfs + wave * 1024);
+        lds_dma16(wsrc, static_cast<uint32_t>((tid >> 5) * 2048 + (tid & 31) * 16), tdst);
+        if (tid < 96) lds_dma16(wsrc, static_cast<uint32_t>(((tid + 256) >> 5) * 2048 + (tid & 31) * 16), tdst + 4096);
+    };
+    auto fsmn_phase = [&]() {
+        if (n_kt == 0) fsmn_stage_issue();  // (no key tile during which it could have been fetched)
         // taps of this thread's two channels
         const int cp = lane, rg = wave;  // channel pair, group of 32 rows (wave-uniform: the time masks are scalar)
         v2f wt[kFsmnTaps];
-#pragma unroll
-        for (int j = 0; j < kFsmnTaps; ++j) {
-            const float2 w = *reinterpret_cast<const float2*>(p.w_fsmn + j * 512 + head * 128 + 2 * cp);
-            wt[j] = v2f{w.x, w.y};
-        }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
+#pragma unroll
+        for (int j = 0; j < kFsmnTaps; ++j) {
+            const float2 w = *reinterpret_cast<const float2*>(smem + kFsmnTapOfs + j * 512 + 8 * cp);
+            wt[j] = v2f{w.x, w.y};
+        }
         const char* fs = smem + kFsmnStage + (32 * rg) * 256 + 4 * cp;
         // all 42 stage rows of this thread's window walk are read up front (one LDS latency, not 42)
         uint32_t raw[32 + kFsmnTaps - 1];
@@ -192,14 +206,18 @@ __global__ __launch_bounds__(kAttnThreads, 2) void attn_kernel(const AttnParams 
     const float c = p.scale_log2;
 
     for (int kt = 0; kt < n_kt; ++kt) {
-        const int cur = kt & 1;
+        const int cur = (kt & 1) ^ buf_par;
         // tile kt is complete in LDS (this thread's LDS-DMA loads are drained by hand: they are issued through
         // inline assembly, which keeps the compiler's LDS-read waits counted) and every wave is done with tile
         // kt - 1, whose buffer is refilled below
         if (!(xf & 32)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (!(xf & 16)) __syncthreads();
         ATTN_STAMP();  // 0: past the barrier
-        if (kt + 1 < n_kt && !(xf & 8)) kv_issue(kt + 1, cur ^ 1, true);
+        if (kt + 1 < n_kt) {
+            if (!(xf & 8)) kv_issue(kt + 1, cur ^ 1, true);
+        } else if (!(xf & 1)) {
+            fsmn_stage_issue();  // the last tile is in buffer 0: the stage's bytes are free
+        }
         ATTN_STAMP();  // 1: prefetch issued
         const char* ks = smem + ((xf & 8) ? 0 : cur) * kBufBytes;
         const char* vs = ks + kTileBytes;

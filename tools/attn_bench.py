@@ -87,6 +87,27 @@ def main():
         tr = [t for t in tr if t]
         print("trace deltas (cycles):", [b - a for a, b in zip(tr, tr[1:])])
         return
+    # clock reference: boxes differ by up to ~10 %, so every run also times a plain GEMM of the library
+    ga = (torch.randn(32000, 512, device=dev) * 0.5).half()
+    gw = (torch.randn(2048, 512, device=dev) * 0.05).half()
+    gb = torch.randn(2048, device=dev)
+    go = torch.empty(32000, 2048, device=dev, dtype=torch.float16)
+
+    def ref_gemm():
+        def one():
+            ctx.check(lib.asrfe_debug_gemm(ctx.handle, ga.data_ptr(), 512, gw.data_ptr(), 512, gb.data_ptr(), 32000, 2048,
+                                           512, go.data_ptr(), 2048, None, None, 1, 0, stream))
+        for _ in range(10):
+            one()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(args.iters):
+            one()
+        e1.record()
+        torch.cuda.synchronize()
+        print(f"reference gemm [32000 x 512] x [512 x 2048]: {1e3 * e0.elapsed_time(e1) / args.iters:7.1f} us")
+
+    ref_gemm()
     for flags in args.flags * args.repeat:
         for _ in range(5):
             launch(qkv, lens, att, fsmn, flags)
