@@ -193,10 +193,14 @@ __global__ __launch_bounds__(kFfnThreads) void post_attn_kernel(const FfnParams 
     const uint32_t smem_base = __builtin_amdgcn_readfirstlane(lds_addr_of(smem));
     const bool no_store = p.flags & 1;  // timing experiments only
     // quarter i (4 KiB: one 1 KiB run per wave) of piece R of the chunk whose eight pieces start at cbase
+    // (the quarter's offset rides in the per-lane part of the address: one scalar base per piece instead of a 64-bit
+    // scalar add per load; the four values are made opaque so that they stay four registers)
+    uint32_t wq[4] = {wlane, wlane + 4096, wlane + 8192, wlane + 12288};
+    asm volatile("" : "+v"(wq[0]), "+v"(wq[1]), "+v"(wq[2]), "+v"(wq[3]));
     auto stage_quarter = [&](auto rc, const char* cbase, int i) {
         constexpr int R = decltype(rc)::value;
         const uint32_t dst = __builtin_amdgcn_readfirstlane(smem_base + R * kPieceBytes + wave * 1024);
-        lds_dma16(cbase + R * kPieceBytes + i * 4096, wlane, dst + i * 4096);
+        lds_dma16(cbase + R * kPieceBytes, wq[i], dst + i * 4096);
     };
     // chunk c of the layer's stream: 0..3 are Wo, 4 + j is hidden chunk j
     auto chunk_base = [&](int c) { return wsrc + static_cast<int64_t>(c) * (8 * kPieceBytes); };
@@ -317,10 +321,22 @@ __global__ __launch_bounds__(kFfnThreads) void post_attn_kernel(const FfnParams 
         constexpr int s = F >> 1, ct = F & 1;
         return *reinterpret_cast<const u16x8*>(smem + R * kPieceBytes + ct * 8192 + rb1 + (sw1 ^ (s << 5)));
     };
+    // Kind 2 addresses are one of eight per-lane bases (k-step kk; ring half: an LDS read's immediate offset ends at
+    // 64 KiB) plus a compile-time offset.  The bases are made opaque where they are formed (frag2_bases), otherwise
+    // the compiler re-associates the sum and spends a vector add on every fragment.
+    int fb2[2][4];
+    auto frag2_bases = [&]() {
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            fb2[0][kk] = rb2 + (sw2 ^ (kk << 5));
+            fb2[1][kk] = fb2[0][kk] + 4 * kPieceBytes;
+            asm volatile("" : "+v"(fb2[0][kk]), "+v"(fb2[1][kk]));
+        }
+    };
     auto frag2 = [&](auto rc, auto fc) -> u16x8 {  // rows 32 ntl + l31, k-step kk of the piece
         constexpr int R = decltype(rc)::value, F = decltype(fc)::value;
         constexpr int kk = F >> 2, ntl = F & 3;
-        return *reinterpret_cast<const u16x8*>(smem + R * kPieceBytes + ntl * 4096 + rb2 + (sw2 ^ (kk << 5)));
+        return *reinterpret_cast<const u16x8*>(smem + fb2[R >> 2][kk] + (R & 3) * kPieceBytes + ntl * 4096);
     };
     u16x8 wf[8];     // rolling weight fragments
 
@@ -333,6 +349,7 @@ __global__ __launch_bounds__(kFfnThreads) void post_attn_kernel(const FfnParams 
     auto proj_pass = [&](int c0, auto to_w1) {
         constexpr bool TO_W1 = decltype(to_w1)::value;
         asm volatile("" : "+v"(rb2), "+v"(sw2));  // see chunk() below
+        frag2_bases();
         static_for<8>([&](auto f) { wf[decltype(f)::value] = frag2(IC<0>{}, f); });
         static_for<4>([&](auto cc) {
             constexpr int C = decltype(cc)::value;
@@ -460,6 +477,7 @@ __global__ __launch_bounds__(kFfnThreads) void post_attn_kernel(const FfnParams 
         // opaque once per chunk keeps the compiler from hoisting all the addresses out of the loop, where they
         // do not fit in registers and come back as scratch reloads - whose vmcnt(0) waits would drain the DMA queue.
         asm volatile("" : "+v"(rb1), "+v"(sw1), "+v"(rb2), "+v"(sw2));
+        frag2_bases();
         // this chunk's and the next chunk's pieces in the weight stream (uniform: scalar registers)
         const char* cb0 = chunk_base(4 + j);
         const char* cb1 = chunk_base(5 + j);
