@@ -52,6 +52,10 @@ extern "C" {
 
 #define ASRFE_PCM_I16 0
 #define ASRFE_PCM_F32 1
+/* float32 in [-1, 1] as the reference's streaming session buffer holds it; the kernel applies the session's int16
+ * hand-off while loading: int16(clip(x, -1, 1) * 32767), truncating (voice-service/app/services/
+ * voice_interface.py:1997-2010), so the features equal those of the WAV file the reference writes for its pipeline. */
+#define ASRFE_PCM_F32_WIRE 2
 
 #define ASRFE_DT_F32 0
 #define ASRFE_DT_BF16 1

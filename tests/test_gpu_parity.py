@@ -532,6 +532,117 @@ def test_engine_ragged_buckets_match_the_padded_step(pkg):
     assert seen == 7
 
 
+# ---- PCM ingress (streaming-session buffer -> pipeline hand-off) -------------------------------------
+def _session_floats(n, seed):
+    """Float32 session samples with everything the hand-off has to get right: overshoot beyond +-1, exact +-1, values
+    whose product with 32767 sits next to an integer, zeros and tiny values of both signs."""
+    rng = np.random.default_rng(seed)
+    x = rng.normal(0, 0.45, n).astype(np.float32)
+    k = np.arange(-32767, 32768, dtype=np.float64)
+    near = np.concatenate([np.nextafter((k / 32767.0).astype(np.float32), np.float32(2)),
+                           np.nextafter((k / 32767.0).astype(np.float32), np.float32(-2)),
+                           (k / 32767.0).astype(np.float32)])
+    pos = rng.choice(n, size=min(n // 2, near.size), replace=False)
+    x[pos] = rng.permutation(near)[: pos.size]
+    x[:8] = [1.0, -1.0, 1.5, -3.0, 0.0, -0.0, 1e-9, -1e-9]
+    return x
+
+
+def test_wire_int16_on_device_is_bit_exact(pkg):
+    from oracle import ingress_oracle as ing
+    x = _session_floats(400000, 1)
+    got = pkg.wire_int16(dev(x))
+    assert got.dtype == torch.int16 and got.is_cuda
+    assert np.array_equal(got.cpu().numpy(), ing.wire_int16(x))
+
+
+def test_session_float_frontend_equals_the_int16_hand_off(pkg):
+    """float32 session buffer with the hand-off applied inside the fbank kernel == the int16 signal the reference
+    writes for its pipeline, fed as int16: identical bits (the kernels differ only in the load), vector and scalar
+    load paths, ragged lengths; and <= 1e-3 against the oracle chain."""
+    from oracle import ingress_oracle as ing
+    fe16 = pkg.WavFrontend()
+    fes = pkg.WavFrontend(session_float=True)
+    n = 16000 * 2
+    x = np.stack([_session_floats(n, 2), _session_floats(n, 3), 0.7 * _session_floats(n, 4)])
+    lens = [n, 23457, 401]
+    w = ing.wire_int16(x)
+    a, an = fe16.forward_fbank(dev(w), lens)
+    b, bn = fes.forward_fbank(dev(x), lens)
+    assert torch.equal(an, bn) and torch.equal(a, b)
+    want, wn = fo.fbank_batch(w, lens)
+    assert bn.cpu().tolist() == wn.tolist()
+    assert np.max(np.abs(b.cpu().numpy() - want)) <= FBANK_TOL
+    fa, la = fe16.forward(dev(w), lens)
+    fb, lb = fes.forward(dev(x), lens)
+    assert torch.equal(la, lb) and torch.equal(fa, fb)
+    # rows that are not 16-byte aligned take the per-sample loads
+    odd = np.zeros((2, 4003), np.float32)
+    odd[0, :4001] = x[0, :4001]
+    odd[1, :3000] = x[1, :3000]
+    c, _ = fes.forward_fbank(dev(odd), [4001, 3000])
+    d, _ = fe16.forward_fbank(dev(ing.wire_int16(odd)), [4001, 3000])
+    assert torch.equal(c, d)
+    # and it is not the FunASR float convention (x 32768, no clipping)
+    e, _ = pkg.WavFrontend().forward_fbank(dev(x), lens)
+    assert not torch.equal(e, b)
+
+
+def test_streaming_chunks_to_encoder_match_the_reference_hand_off(pkg):
+    """The reference's streaming flow on one utterance: base64 WAV chunks of 400 ms -> float32 session buffer ->
+    (finalize) int16 hand-off -> recognition.  Here: decode_wav_base64 -> PcmAccumulator on the device -> engine with
+    session_float; compared with the oracle chain run on the oracle's int16 hand-off."""
+    import base64
+    import io
+    import wave
+    from oracle import ingress_oracle as ing
+
+    def chunk_b64(samples, rate, channels):
+        buf = io.BytesIO()
+        with wave.open(buf, "wb") as wf:
+            wf.setnchannels(channels)
+            wf.setsampwidth(2)
+            wf.setframerate(rate)
+            wf.writeframes(samples.tobytes())
+        return base64.b64encode(buf.getvalue()).decode()
+
+    pcm = fo.synth_pcm("bursts", 16000 * 3, 91)
+    payloads = [chunk_b64(pcm[i:i + 6400], 16000, 1) for i in range(0, 44800, 6400)]
+    payloads.append(chunk_b64(np.repeat(pcm[44800:], 2), 16000, 2))       # a stereo chunk (both channels equal)
+    acc = pkg.PcmAccumulator(capacity=10000)
+    ref_chunks = []
+    for p in payloads:
+        got, sr = pkg.decode_wav_base64(p)
+        want, _ = ing.decode_wav_base64(p)
+        assert sr == 16000 and np.array_equal(got, want)
+        acc.append(got)
+        ref_chunks.append(want)
+    session = ing.accumulate(ref_chunks)
+    assert len(acc) == session.size == 48000
+    assert np.array_equal(acc.samples().cpu().numpy(), session)
+    wire = ing.wire_int16(session)
+    pcm16, lens = acc.wire()
+    assert np.array_equal(pcm16.cpu().numpy()[0], wire) and lens.cpu().tolist() == [48000]
+
+    rng = np.random.default_rng(6)
+    shift = -rng.uniform(6, 14, 560).astype(np.float32)
+    scale = (1.0 / rng.uniform(1.5, 4.5, 560)).astype(np.float32)
+    cfg_o = so.SanmConfig(num_blocks=2)
+    sd = so.make_state_dict(cfg_o, seed=4)
+    cfg = pkg.default_config()
+    cfg.enc_num_blocks = 2
+    eng = pkg.AsrEngine(batch=1, max_samples=48000, cfg=cfg, cmvn=(shift, scale), state_dict=sd, session_float=True)
+    out, olens = eng.run(acc.samples().reshape(1, -1), lens)
+    out, olens = out.clone(), olens.clone()
+    out16, olens16 = eng.run(pcm16, lens)              # the int16 hand-off itself: same bits
+    torch.cuda.synchronize()
+    assert torch.equal(olens, olens16) and torch.equal(out, out16)
+    wf_, wl = fo.frontend(wire[None], [48000], shift, scale)
+    assert olens.cpu().tolist() == wl.tolist()
+    want, _ = so.encoder_forward(torch.from_numpy(wf_).float(), torch.from_numpy(wl), sd, cfg_o)
+    assert float((out.cpu() - want).abs().max()) <= ENC_TOL
+
+
 def test_attention_fsmn_kernel_vs_fp64(pkg):
     """The attention + FSMN kernel on its own (debug hook) against an fp64 evaluation of the same 16-bit inputs:
     ragged lengths, a length below the FSMN half-width, T' around the 64-key and 128-query tile edges."""

@@ -12,7 +12,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libasrfe.so")
 
-PCM_I16, PCM_F32 = 0, 1
+PCM_I16, PCM_F32, PCM_F32_WIRE = 0, 1, 2
 DT_F32, DT_BF16, DT_F16 = 0, 1, 2
 
 ERROR_NAMES = {

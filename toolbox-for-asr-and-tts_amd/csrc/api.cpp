@@ -546,7 +546,7 @@ static int32_t fill_common(asrfe_ctx* ctx, FbankParams& p, const void* pcm, int3
     if (batch < 0 || batch > 65535) return set_err(ctx, ASRFE_ERR_SHAPE, std::string(who) + ": batch must be in 0..65535");
     if (batch == 0) return ASRFE_OK;
     if (!pcm || !lens) return set_err(ctx, ASRFE_ERR_BAD_ARG, std::string(who) + ": null pcm / lens");
-    if (pcm_dtype != ASRFE_PCM_I16 && pcm_dtype != ASRFE_PCM_F32) return set_err(ctx, ASRFE_ERR_BAD_ARG, std::string(who) + ": bad pcm_dtype");
+    if (pcm_dtype != ASRFE_PCM_I16 && pcm_dtype != ASRFE_PCM_F32 && pcm_dtype != ASRFE_PCM_F32_WIRE) return set_err(ctx, ASRFE_ERR_BAD_ARG, std::string(who) + ": bad pcm_dtype");
     if (stride < 0) return set_err(ctx, ASRFE_ERR_SHAPE, std::string(who) + ": negative pcm_stride");
     const int64_t es = pcm_dtype == ASRFE_PCM_I16 ? 2 : 4;
     p.pcm = pcm;

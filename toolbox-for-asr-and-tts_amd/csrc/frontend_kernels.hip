@@ -154,6 +154,16 @@ template <>
 __device__ __forceinline__ float pcm_to_kaldi<int16_t>(int16_t v) { return static_cast<float>(v); }
 template <>
 __device__ __forceinline__ float pcm_to_kaldi<float>(float v) { return v * 32768.0f; }
+// A float32 session sample in [-1, 1] (ASRFE_PCM_F32_WIRE): the value of the int16 the reference hands to its pipeline,
+// int16(clip(v, -1, 1) * 32767), truncated toward zero (voice_interface.py:1997-2010).
+struct UnitF32 {
+    float v;
+};
+__device__ __forceinline__ float unit_to_wire(float v) {
+    return __builtin_truncf(__builtin_fminf(__builtin_fmaxf(v, -1.0f), 1.0f) * 32767.0f);
+}
+template <>
+__device__ __forceinline__ float pcm_to_kaldi<UnitF32>(UnitF32 s) { return unit_to_wire(s.v); }
 
 // Eight consecutive samples as they lie in memory (one or two 16-byte loads), and their Kaldi-scaled floats.
 template <typename PcmT>
@@ -181,6 +191,19 @@ struct Raw8<float> {
     __device__ __forceinline__ void get(float (&out)[8]) const {
         out[0] = a.x * 32768.0f; out[1] = a.y * 32768.0f; out[2] = a.z * 32768.0f; out[3] = a.w * 32768.0f;
         out[4] = b.x * 32768.0f; out[5] = b.y * 32768.0f; out[6] = b.z * 32768.0f; out[7] = b.w * 32768.0f;
+    }
+};
+
+template <>
+struct Raw8<UnitF32> {
+    float4 a, b;
+    __device__ __forceinline__ void load(const UnitF32* p) {
+        a = *reinterpret_cast<const float4*>(p);
+        b = *reinterpret_cast<const float4*>(p + 4);
+    }
+    __device__ __forceinline__ void get(float (&out)[8]) const {
+        out[0] = unit_to_wire(a.x); out[1] = unit_to_wire(a.y); out[2] = unit_to_wire(a.z); out[3] = unit_to_wire(a.w);
+        out[4] = unit_to_wire(b.x); out[5] = unit_to_wire(b.y); out[6] = unit_to_wire(b.z); out[7] = unit_to_wire(b.w);
     }
 };
 
@@ -515,7 +538,6 @@ int32_t launch_fbank(asrfe_ctx* ctx, const FbankParams& p, int pcm_dtype, bool f
     if (p.batch <= 0 || p.t_max <= 0) return ASRFE_OK;
     dim3 grid((p.t_max + kFramesPerBlock - 1) / kFramesPerBlock, p.batch, 1);
     dim3 block(kWavesPerBlock * 64);
-    const bool i16 = pcm_dtype == ASRFE_PCM_I16;
     const bool bf = out_dtype == ASRFE_DT_BF16;
     bool std_mel = true;
     for (int g = 0; g < kMelGroups; ++g)
@@ -530,8 +552,9 @@ int32_t launch_fbank(asrfe_ctx* ctx, const FbankParams& p, int pcm_dtype, bool f
                                block, 0, s, p);
     };
     auto go_pcm = [&](auto fused_tag, auto bf_tag) {
-        if (i16) go(int16_t{}, fused_tag, bf_tag);
-        else go(float{}, fused_tag, bf_tag);
+        if (pcm_dtype == ASRFE_PCM_I16) go(int16_t{}, fused_tag, bf_tag);
+        else if (pcm_dtype == ASRFE_PCM_F32) go(float{}, fused_tag, bf_tag);
+        else go(UnitF32{}, fused_tag, bf_tag);
     };
     if (!fused) go_pcm(std::false_type{}, std::false_type{});
     else if (bf) go_pcm(std::true_type{}, std::true_type{});

@@ -41,7 +41,12 @@ class AsrEngine:
 
     def __init__(self, batch: int, max_samples: int, cfg: _lib.Config | None = None, device=None,
                  out_dtype=torch.float32, cmvn: tuple | None = None, state_dict=None, n_streams: int = 1,
-                 n_buckets: int = 0):
+                 n_buckets: int = 0, session_float: bool = False):
+        # session_float: float32 PCM is a streaming-session buffer in [-1, 1]; the frontend kernel then applies the
+        # reference's int16 hand-off (clip, x 32767, truncate; voice_interface.py:1997-2010) while loading, so the
+        # result equals that of the int16 WAV the reference writes.  Otherwise float32 PCM is scaled by 32768 as
+        # FunASR's loader does.
+        self.session_float = bool(session_float)
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
         with torch.cuda.device(self.device):
             self.ctx = _lib.Context(cfg)
@@ -90,7 +95,8 @@ class AsrEngine:
             raise ValueError("AsrEngine: pcm and pcm_lens (int32) must live on the engine's device")
         if pcm.dim() != 2 or pcm.shape[0] != self.batch or pcm.shape[1] > self.max_samples or pcm.stride(1) != 1:
             raise ValueError("AsrEngine: pcm must be [batch, n <= max_samples] with unit inner stride")
-        dt = {torch.int16: _lib.PCM_I16, torch.float32: _lib.PCM_F32}.get(pcm.dtype)
+        dt = {torch.int16: _lib.PCM_I16,
+              torch.float32: _lib.PCM_F32_WIRE if self.session_float else _lib.PCM_F32}.get(pcm.dtype)
         if dt is None:
             raise ValueError("AsrEngine: PCM dtype must be int16 or float32")
         return dt

@@ -51,12 +51,16 @@ class WavFrontend:
     Arguments as in FunASR: ``frame_length`` / ``frame_shift`` in milliseconds.  ``dither`` must be 0
     (the kernels are deterministic); ``upsacle_samples`` (sic) keeps FunASR's spelling and means float
     PCM in [-1, 1) is multiplied by 32768, which is what the int16 input path is equal to.
+    ``session_float`` (no FunASR counterpart) treats float32 input as the reference's streaming-session buffer
+    instead: the kernel quantises it on load exactly as the session's hand-off does, int16(clip(x, -1, 1) * 32767)
+    truncating (voice_interface.py:1997-2010), so the features equal those of the int16 WAV the reference writes.
     """
 
     def __init__(self, cmvn_file: str | None = None, fs: int = 16000, window: str = "hamming", n_mels: int = 80,
                  frame_length: int = 25, frame_shift: int = 10, lfr_m: int = 7, lfr_n: int = 6, dither: float = 0.0,
                  snip_edges: bool = True, upsacle_samples: bool = True, cmvn: tuple | None = None,
-                 ctx: _lib.Context | None = None, **kwargs):
+                 ctx: _lib.Context | None = None, session_float: bool = False, **kwargs):
+        self.session_float = bool(session_float)
         if dither != 0.0:
             raise ValueError("WavFrontend: only dither=0.0 is supported")
         if not snip_edges:
@@ -104,8 +108,7 @@ class WavFrontend:
     def num_lfr_frames(self, n_frames: int) -> int:
         return int(self.ctx.lib.asrfe_num_lfr_frames(self.ctx.handle, int(n_frames)))
 
-    @staticmethod
-    def _prep(input: torch.Tensor, input_lengths):
+    def _prep(self, input: torch.Tensor, input_lengths):
         if not isinstance(input, torch.Tensor) or not input.is_cuda:
             raise ValueError("WavFrontend: input must be a CUDA/HIP tensor [B, N]")
         if input.dim() == 1:
@@ -115,7 +118,7 @@ class WavFrontend:
         if input.dtype == torch.int16:
             dt = _lib.PCM_I16
         elif input.dtype == torch.float32:
-            dt = _lib.PCM_F32
+            dt = _lib.PCM_F32_WIRE if self.session_float else _lib.PCM_F32
         else:
             raise ValueError("WavFrontend: PCM dtype must be int16 or float32")
         if input.stride(1) != 1 and input.shape[1] > 1:

@@ -80,13 +80,29 @@ def main():
         ctx.check(lib.asrfe_frontend(ctx.handle, pcm.data_ptr(), 0, pcm.stride(0), lens.data_ptr(), fb, Tp,
                                      feats.data_ptr(), _lib.DT_F32, nfr.data_ptr(), stream))
 
+    # session path: a float32 session buffer, either quantised by a separate pass and fed as int16, or fed as it is
+    # with the hand-off applied while the kernel loads
+    from toolbox_for_asr_and_tts_amd.ingress import wire_int16
+    session = (pcm.to(torch.float32) / 32767.0).contiguous()
+    pcm16 = torch.empty_like(pcm)
+
+    def wire_then_fused():
+        pcm16.copy_(wire_int16(session))
+        ctx.check(lib.asrfe_frontend(ctx.handle, pcm16.data_ptr(), 0, pcm16.stride(0), lens.data_ptr(), fb, Tp,
+                                     feats.data_ptr(), _lib.DT_F32, nfr.data_ptr(), stream))
+
+    def session_fused():
+        ctx.check(lib.asrfe_frontend(ctx.handle, session.data_ptr(), _lib.PCM_F32_WIRE, session.stride(0),
+                                     lens.data_ptr(), fb, Tp, feats.data_ptr(), _lib.DT_F32, nfr.data_ptr(), stream))
+
     t0 = time.time()
     while time.time() - t0 < 1.0:
         for _ in range(20):
             fbank()
         torch.cuda.synchronize()
     for _ in range(args.repeat):
-        for name, fn in (("fbank", fbank), ("fused frontend", fused)):
+        for name, fn in (("fbank", fbank), ("fused frontend", fused), ("wire + fused", wire_then_fused),
+                         ("session fused", session_fused)):
             for _ in range(3):
                 fn()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
