@@ -57,3 +57,50 @@ def accumulate(chunks) -> np.ndarray:
     for c in chunks:
         out = np.concatenate([out, np.asarray(c, dtype=np.float32)])
     return out
+
+
+class SessionBuffer:
+    """voice_interface.py ``StreamingASRSession``: only the state that decides WHICH samples reach the recognizer
+    (init :1103-1116, energy gate :1569-1578 and :1606, accumulation policy :1672-1747, finalize condition
+    :1816-1818).  The clock is an argument so the restatement is deterministic.  The VAD model's answer is computed
+    by the reference but not used (:1605-1606), so it is absent here."""
+    ENERGY_THRESHOLD = 0.03   # :656
+    MAX_THRESHOLD = 0.17      # :657
+    SILENCE_THRESHOLD = 2.0   # :649
+    PRE_SPEECH_SECONDS = 0.4  # :1116
+
+    def __init__(self, now: float):
+        self.audio_buffer = np.array([], dtype=np.float32)
+        self.pre_speech_buffer = np.array([], dtype=np.float32)
+        self.silence_timer = 0.0
+        self.last_voice_time = now
+        self.has_detected_speech = False
+        self.silence_chunk_count = 0
+
+    def process_chunk(self, audio_np: np.ndarray, now: float):
+        audio_energy = np.mean(np.abs(audio_np))
+        audio_max = np.max(np.abs(audio_np))
+        is_speech = bool(audio_energy > self.ENERGY_THRESHOLD and audio_max > self.MAX_THRESHOLD)
+        if is_speech:
+            self.silence_timer = 0.0
+            self.last_voice_time = now
+            self.has_detected_speech = True
+            self.silence_chunk_count = 0
+            if len(self.pre_speech_buffer) > 0:
+                self.audio_buffer = np.concatenate([self.audio_buffer, self.pre_speech_buffer])
+                self.pre_speech_buffer = np.array([], dtype=np.float32)
+            self.audio_buffer = np.concatenate([self.audio_buffer, audio_np])
+        elif self.has_detected_speech:
+            if self.silence_chunk_count < 2:
+                self.audio_buffer = np.concatenate([self.audio_buffer, audio_np])
+                self.silence_chunk_count += 1
+            self.silence_timer = now - self.last_voice_time
+        else:
+            self.pre_speech_buffer = np.concatenate([self.pre_speech_buffer, audio_np])
+            target = int(self.PRE_SPEECH_SECONDS * TARGET_SR)
+            if len(self.pre_speech_buffer) > target:
+                self.pre_speech_buffer = self.pre_speech_buffer[-target:]
+            self.silence_timer = 0.0
+        should_finalize = bool(self.silence_timer >= self.SILENCE_THRESHOLD and len(self.audio_buffer) > 0
+                               and self.has_detected_speech)
+        return {"is_speech": is_speech, "intermediate_text": "", "should_finalize": should_finalize}

@@ -643,6 +643,30 @@ def test_streaming_chunks_to_encoder_match_the_reference_hand_off(pkg):
     assert float((out.cpu() - want).abs().max()) <= ENC_TOL
 
 
+def test_streaming_session_on_the_device_holds_what_the_reference_would_send(pkg):
+    """The session's accumulation policy (energy gate, 400 ms of pre-speech, two trailing silent chunks) with the
+    utterance on the device: after every chunk the device buffer equals the reference policy's numpy buffer, and the
+    features of the float buffer (hand-off inside the kernel) equal those of the oracle's int16 hand-off."""
+    from oracle import ingress_oracle as ing
+    rng = np.random.default_rng(12)
+    ref = ing.SessionBuffer(now=50.0)
+    ses = pkg.StreamingPcmSession(capacity=5000, now=50.0)
+    t = 50.0
+    levels = [0.002, 0.003, 0.25, 0.3, 0.002, 0.2, 0.001, 0.001, 0.001, 0.001, 0.001, 0.001]
+    for lv in levels:
+        x = rng.normal(0, lv, 6400).astype(np.float32)
+        t += 0.4
+        assert ses.process_chunk(x, t) == ref.process_chunk(x, t)
+        assert np.array_equal(ses.samples().cpu().numpy(), ref.audio_buffer)
+    assert ses.process_chunk(np.zeros(6400, np.float32), t + 2.0)["should_finalize"]
+    assert len(ses.audio) == 7 * 6400          # 1 pre-speech + 2 speech + 1 silent + 1 speech + 2 silent chunks
+    n = len(ses.audio)
+    fes = pkg.WavFrontend(session_float=True)
+    a, an = fes.forward_fbank(ses.samples().reshape(1, -1), [n])
+    b, bn = pkg.WavFrontend().forward_fbank(dev(ing.wire_int16(ref.audio_buffer)[None]), [n])
+    assert torch.equal(an, bn) and torch.equal(a, b)
+
+
 def test_attention_fsmn_kernel_vs_fp64(pkg):
     """The attention + FSMN kernel on its own (debug hook) against an fp64 evaluation of the same 16-bit inputs:
     ragged lengths, a length below the FSMN half-width, T' around the 64-key and 128-query tile edges."""

@@ -89,3 +89,69 @@ def test_accumulator_on_the_host_device_equals_concatenation():
     assert len(acc) == 0
     acc.append(chunks[0])
     assert np.array_equal(acc.samples().numpy(), chunks[0])
+
+
+def _scripted_chunks(seed, n_chunks):
+    """Chunks of 240-400 ms around the gate's two thresholds: loud, quiet, loud-mean-but-low-peak, spiky-but-quiet."""
+    rng = np.random.default_rng(seed)
+    out = []
+    t = 100.0
+    for _ in range(n_chunks):
+        n = int(rng.choice([3840, 6400, 6400, 1000]))
+        kind = rng.choice(["loud", "quiet", "flat", "spike", "edge"], p=[0.35, 0.35, 0.1, 0.1, 0.1])
+        if kind == "loud":
+            x = rng.normal(0, 0.2, n)
+        elif kind == "quiet":
+            x = rng.normal(0, 0.004, n)
+        elif kind == "flat":                       # mean |x| above 0.03, peak below 0.17
+            x = rng.uniform(-0.12, 0.12, n)
+        elif kind == "spike":                      # peak above 0.17, mean below 0.03
+            x = rng.normal(0, 0.002, n)
+            x[rng.integers(0, n)] = 0.9
+        else:                                      # mean right at the threshold
+            x = np.full(n, 0.03) * rng.choice([-1, 1], n)
+            x[0] = 0.5
+            x[1:] *= rng.choice([0.9999, 1.0001])
+        t += n / 16000 + float(rng.choice([0.0, 0.0, 0.7, 1.4]))
+        out.append((x.astype(np.float32), t))
+    return out
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2, 3])
+def test_streaming_session_buffer_follows_the_reference_policy(seed):
+    ref = io_oracle.SessionBuffer(now=100.0)
+    ses = ing.StreamingPcmSession(device="cpu", capacity=64, now=100.0)
+    finals = 0
+    for x, t in _scripted_chunks(seed, 60):
+        want = ref.process_chunk(x, t)
+        got = ses.process_chunk(x, t)
+        assert got == want
+        assert len(ses.audio) == len(ref.audio_buffer)
+        if got["should_finalize"]:
+            finals += 1
+            assert np.array_equal(ses.samples().numpy(), ref.audio_buffer)
+            assert np.array_equal(ses.wire()[0][0].numpy(), io_oracle.wire_int16(ref.audio_buffer))
+            ref = io_oracle.SessionBuffer(now=t)
+            ses.reset(now=t)
+    assert np.array_equal(ses.samples().numpy(), ref.audio_buffer)
+    assert finals >= 1
+
+
+def test_streaming_session_known_sequence():
+    """Silence, silence, speech, silence x3, then a long gap: the newest 400 ms before the speech are kept, only two
+    trailing silent chunks are, and finalize fires once 2 s have passed since the last speech chunk."""
+    q = lambda v: np.full(6400, v, np.float32)
+    ses = ing.StreamingPcmSession(device="cpu", now=0.0)
+    assert ses.process_chunk(q(0.001), 0.4) == {"is_speech": False, "intermediate_text": "", "should_finalize": False}
+    ses.process_chunk(q(0.002), 0.8)
+    assert len(ses.audio) == 0
+    r = ses.process_chunk(q(0.3), 1.2)
+    assert r["is_speech"] and len(ses.audio) == 12800
+    assert float(ses.samples()[0]) == np.float32(0.002) and float(ses.samples()[6400]) == np.float32(0.3)
+    for k, t in enumerate((1.6, 2.0, 2.4)):
+        r = ses.process_chunk(q(0.003), t)
+        assert not r["is_speech"] and not r["should_finalize"]
+    assert len(ses.audio) == 12800 + 2 * 6400
+    assert ses.process_chunk(q(0.003), 3.19)["should_finalize"] is False
+    assert ses.process_chunk(q(0.003), 3.2)["should_finalize"] is True
+    assert len(ses.audio) == 12800 + 2 * 6400

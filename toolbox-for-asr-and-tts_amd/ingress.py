@@ -97,3 +97,71 @@ class PcmAccumulator:
         """(int16 [1, n] on the device, int32 lengths [1] on the device)."""
         pcm = wire_int16(self._buf[: self._n]).reshape(1, -1)
         return pcm, torch.tensor([self._n], dtype=torch.int32, device=self.device)
+
+
+class StreamingPcmSession:
+    """The part of the reference's ``StreamingASRSession`` that decides which samples reach the recognizer
+    (voice_interface.py: state :1103-1116, ``process_chunk`` :1569-1578, :1606, :1672-1747, :1816-1818), with the
+    utterance held on the device:
+
+    * a chunk counts as speech when mean|x| > 0.03 and max|x| > 0.17 (the reference also asks its VAD model but
+      discards the answer, :1605-1606; no model is consulted here);
+    * before the first speech chunk only the newest 400 ms are kept (host side, at most 6400 samples) and they are
+      put in front of that first speech chunk;
+    * after speech, every speech chunk and at most two silent chunks in a row are appended;
+    * ``should_finalize`` once 2 s have passed since the last speech chunk.
+
+    ``process_chunk`` returns the reference's dictionary (``intermediate_text`` is always empty there too).  ``now``
+    defaults to ``time.time()`` as in the reference; tests pass their own clock.  KWS, speaker verification and the
+    recognizer call itself are not part of this class: ``wire()`` / ``samples()`` give what ``finalize`` would send."""
+    VAD_ENERGY_THRESHOLD = 0.03
+    VAD_MAX_THRESHOLD = 0.17
+    SILENCE_THRESHOLD = 2.0
+    PRE_SPEECH_MAX_DURATION = 0.4
+
+    def __init__(self, device="cuda", capacity: int = 16000 * 30, now: float | None = None):
+        import time
+        self._clock = time.time
+        self.audio = PcmAccumulator(device, capacity)
+        self.reset(now)
+
+    def reset(self, now: float | None = None):
+        self.audio.clear()
+        self._pre = np.zeros((0,), np.float32)
+        self.silence_timer = 0.0
+        self.last_voice_time = self._clock() if now is None else now
+        self.has_detected_speech = False
+        self.silence_chunk_count = 0
+
+    def process_chunk(self, audio_np, now: float | None = None):
+        now = self._clock() if now is None else now
+        x = np.asarray(audio_np)
+        mag = np.abs(x)
+        is_speech = bool(np.mean(mag) > self.VAD_ENERGY_THRESHOLD and np.max(mag) > self.VAD_MAX_THRESHOLD)
+        if is_speech:
+            self.silence_timer = 0.0
+            self.last_voice_time = now
+            self.has_detected_speech = True
+            self.silence_chunk_count = 0
+            if self._pre.size:
+                self.audio.append(self._pre)
+                self._pre = np.zeros((0,), np.float32)
+            self.audio.append(x)
+        elif self.has_detected_speech:
+            if self.silence_chunk_count < 2:
+                self.audio.append(x)
+                self.silence_chunk_count += 1
+            self.silence_timer = now - self.last_voice_time
+        else:
+            keep = int(self.PRE_SPEECH_MAX_DURATION * TARGET_SAMPLE_RATE)
+            self._pre = np.concatenate([self._pre, x.astype(np.float32, copy=False)])[-keep:]
+            self.silence_timer = 0.0
+        should_finalize = bool(self.silence_timer >= self.SILENCE_THRESHOLD and len(self.audio) > 0
+                               and self.has_detected_speech)
+        return {"is_speech": is_speech, "intermediate_text": "", "should_finalize": should_finalize}
+
+    def samples(self) -> torch.Tensor:
+        return self.audio.samples()
+
+    def wire(self):
+        return self.audio.wire()
