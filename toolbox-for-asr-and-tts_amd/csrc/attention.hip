@@ -86,6 +86,29 @@ __global__ __launch_bounds__(kAttnThreads, 2) void attn_kernel(const AttnParams 
     // 4 KiB behind it free for the FSMN stage to arrive while that tile is computed
     const int buf_par = (n_kt - 1) & 1;
     if (n_kt > 0) kv_issue(0, buf_par, true);
+    // Inside the key loop the same loads are issued one at a time between the MFMAs of the score product, from
+    // running byte offsets (row i * 16 + st_row of the next tile; + 64 rows per tile) clamped to the last row:
+    // no multiply and no burst of eight loads in front of the matrix work.
+    const uint32_t tile_step = 64u * ldb;
+    const uint32_t last_row = static_cast<uint32_t>(p.Tp - 1) * ldb;
+    const uint32_t kclamp = last_row + k_chunk * 16, vclamp = last_row + v_chunk * 16;
+    const uint32_t vdelta = (v_chunk - k_chunk) * 16;  // (wraps: added to a K offset it gives the V offset)
+    uint32_t kro[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) kro[i] = static_cast<uint32_t>(64 + i * 16 + st_row) * ldb + k_chunk * 16;
+    // load j of a tile: j >> 1 = row group i, j & 1 = V
+    auto kv_issue_one = [&](auto jc, uint32_t dst_buf) {
+        constexpr int J = decltype(jc)::value, I = J >> 1;
+        if constexpr ((J & 1) == 0) {
+            const uint32_t o = kro[I] < kclamp ? kro[I] : kclamp;
+            lds_dma16(kbase, o, dst_buf + I * 4096);
+        } else {
+            const uint32_t ov = kro[I] + vdelta;
+            const uint32_t o = ov < vclamp ? ov : vclamp;
+            lds_dma16(vbase, o, dst_buf + kTileBytes + I * 4096);
+            kro[I] += tile_step;
+        }
+    };
 
     // Q fragments: lane holds Q[q0 + l31][16 s + 8 h .. +8), s = 0..7
     u16x8 qf[8];
@@ -205,7 +228,9 @@ __global__ __launch_bounds__(kAttnThreads, 2) void attn_kernel(const AttnParams 
     float m_run = -INFINITY, l_run = 0.0f;
     const float c = p.scale_log2;
 
-    for (int kt = 0; kt < n_kt; ++kt) {
+    // one key tile; MORE: another tile follows (its K / V loads are issued here), otherwise this is the last tile
+    auto key_tile = [&](const int kt, auto more_c) __attribute__((always_inline)) {
+        constexpr bool more = decltype(more_c)::value;
         const int cur = (kt & 1) ^ buf_par;
         // tile kt is complete in LDS (this thread's LDS-DMA loads are drained by hand: they are issued through
         // inline assembly, which keeps the compiler's LDS-read waits counted) and every wave is done with tile
@@ -213,34 +238,42 @@ __global__ __launch_bounds__(kAttnThreads, 2) void attn_kernel(const AttnParams 
         if (!(xf & 32)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (!(xf & 16)) __syncthreads();
         ATTN_STAMP();  // 0: past the barrier
-        if (kt + 1 < n_kt) {
-            if (!(xf & 8)) kv_issue(kt + 1, cur ^ 1, true);
-        } else if (!(xf & 1)) {
-            fsmn_stage_issue();  // the last tile is in buffer 0: the stage's bytes are free
-        }
+        if (!more && !(xf & 1)) fsmn_stage_issue();  // the last tile is in buffer 0: the stage's bytes are free
         ATTN_STAMP();  // 1: prefetch issued
         const char* ks = smem + ((xf & 8) ? 0 : cur) * kBufBytes;
         const char* vs = ks + kTileBytes;
+        const uint32_t nxt = __builtin_amdgcn_readfirstlane(smem_base + (cur ^ 1) * kBufBytes + wave * 1024);
 
         // ---- S^T = K Q^T : two 32-key sub-tiles ---------------------------------------------
-        // (consecutive MFMAs alternate between the two accumulators: none waits for the one right before it)
+        // (consecutive MFMAs alternate between the two accumulators: none waits for the one right before it; the
+        // K fragments are read three k-steps ahead of their use, and one load of the next tile is issued per k-step)
         f32x16 sacc[2];
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
             for (int e = 0; e < 16; ++e) sacc[kk][e] = 0.0f;
         if (!(xf & 4)) {
+            const char* krow = ks + l31 * 256;
+            const int ksw = l31 & 15;
+            auto kread = [&](int s, int kk) {
+                return *reinterpret_cast<const u16x8*>(krow + kk * 8192 + (((2 * s + h) ^ ksw) << 4));
+            };
+            u16x8 kf[3][2];
 #pragma unroll
-            for (int s = 0; s < 8; ++s)
-#pragma unroll
-                for (int kk = 0; kk < 2; ++kk) {
-                    const char* krow = ks + (kk * 32 + l31) * 256;
-                    const u16x8 kf = *reinterpret_cast<const u16x8*>(krow + (((2 * s + h) ^ (l31 & 15)) << 4));
-                    sacc[kk] = mfma32<F16>(kf, qf[s], sacc[kk]);
-                }
+            for (int s = 0; s < 3; ++s) { kf[s][0] = kread(s, 0); kf[s][1] = kread(s, 1); }
+            static_for<8>([&](auto sc) {
+                constexpr int S = decltype(sc)::value;
+                sacc[0] = mfma32<F16>(kf[S % 3][0], qf[S], sacc[0]);
+                sacc[1] = mfma32<F16>(kf[S % 3][1], qf[S], sacc[1]);
+                if constexpr (S + 3 < 8) { kf[S % 3][0] = kread(S + 3, 0); kf[S % 3][1] = kread(S + 3, 1); }
+                if (more && !(xf & 8)) kv_issue_one(sc, nxt);
+                __builtin_amdgcn_sched_barrier(0);
+            });
+        } else if (more && !(xf & 8)) {
+            static_for<8>([&](auto sc) { kv_issue_one(sc, nxt); });
         }
         ATTN_STAMP();  // 2: QK issued
-        if (kt == n_kt - 1) {  // wave-uniform: mask keys at or past the utterance length
+        if constexpr (!more) {  // mask keys at or past the utterance length
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
@@ -254,7 +287,10 @@ __global__ __launch_bounds__(kAttnThreads, 2) void attn_kernel(const AttnParams 
         for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
             for (int e = 0; e < 16; ++e) rmax = fmaxf(rmax, sacc[kk][e]);
-        rmax = fmaxf(rmax, __shfl_xor(rmax, 32));
+        {   // the other 32 keys of the row sit in lane ^ 32: one register swap instead of a trip through the LDS
+            const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(rmax), __float_as_uint(rmax), false, false);
+            rmax = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
+        }
         // The running maximum only has to bound the scores well enough for exp2 to stay in range: it is raised
         // (and the accumulators rescaled) only when the tile's maximum exceeds it by more than 2^8 after scaling,
         // so most tiles skip the rescale.  Every tile holds at least one valid key, so rmax is finite.
@@ -272,17 +308,23 @@ __global__ __launch_bounds__(kAttnThreads, 2) void attn_kernel(const AttnParams 
         }
         // ---- P = exp2(...) and O^T += V^T P^T, one 32-key sub-tile at a time: the MFMAs of sub-tile 0 have the
         //      exponentials of sub-tile 1 to overlap with (one straight-line block for the scheduler)
-        float psum = 0.0f;
+        // (scores travel as register pairs: one packed FMA and one packed add per two keys)
+        v2f psum2 = {0.0f, 0.0f};
+        const v2f c2 = {c, c}, nmc2 = {-mc, -mc};
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
             u16x8 pf[2];
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const float pv = (xf & 64) ? sacc[kk][8 * s2 + j] * c - mc : __builtin_amdgcn_exp2f(sacc[kk][8 * s2 + j] * c - mc);
-                    psum += pv;
-                    pf[s2][j] = to_elem<F16>(pv);
+                for (int j = 0; j < 8; j += 2) {
+                    const v2f sv = {sacc[kk][8 * s2 + j], sacc[kk][8 * s2 + j + 1]};
+                    const v2f t = __builtin_elementwise_fma(sv, c2, nmc2);
+                    const v2f pv = (xf & 64) ? t : v2f{__builtin_amdgcn_exp2f(t.x), __builtin_amdgcn_exp2f(t.y)};
+                    psum2 += pv;
+                    const uint32_t w = pack_elem2<F16>(pv.x, pv.y);
+                    pf[s2][j] = static_cast<uint16_t>(w & 0xffffu);
+                    pf[s2][j + 1] = static_cast<uint16_t>(w >> 16);
                 }
             if (!(xf & 2)) {
 #pragma unroll
@@ -300,9 +342,11 @@ __global__ __launch_bounds__(kAttnThreads, 2) void attn_kernel(const AttnParams 
                     }
             }
         }
-        l_run = l_run * alpha + psum;
+        l_run = l_run * alpha + (psum2.x + psum2.y);
         ATTN_STAMP();  // 4: exponentials and PV issued
-    }
+    };
+    for (int kt = 0; kt + 1 < n_kt; ++kt) key_tile(kt, std::true_type{});
+    if (n_kt > 0) key_tile(n_kt - 1, std::false_type{});
     ATTN_STAMP();
 
     // ---- normalise; each wave routes its 32 x 128 tile through LDS so that 16 lanes store one full 256-byte row ----
@@ -339,7 +383,8 @@ __global__ __launch_bounds__(kAttnThreads, 2) void attn_kernel(const AttnParams 
 int32_t launch_attention(asrfe_ctx* ctx, const AttnParams& p, hipStream_t s) {
     if (p.B <= 0 || p.Tp <= 0) return ASRFE_OK;
     if (!p.qkv || !p.lens || !p.out || !p.fsmn || !p.w_fsmn) return set_err(ctx, ASRFE_ERR_BAD_ARG, "attention: null argument");
-    if (static_cast<int64_t>(p.Tp) * p.ld_qkv * 2 >= (int64_t{1} << 32))
+    // (the kernel's running 32-bit load offsets run up to two tiles past the last row before they are clamped)
+    if ((static_cast<int64_t>(p.Tp) + 128) * p.ld_qkv * 2 >= (int64_t{1} << 32))
         return set_err(ctx, ASRFE_ERR_SHAPE, "attention: one utterance's qkv rows must stay below 4 GiB");
     AttnParams q = p;
     q.n_qtiles = (p.Tp + 127) / 128;

@@ -2,6 +2,9 @@
 // Storage is uint16_t everywhere; F16 = true selects fp16.
 #pragma once
 
+#include <type_traits>
+#include <utility>
+
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -54,6 +57,19 @@ __device__ __forceinline__ f32x16 mfma32(const u16x8 a, const u16x8 b, const f32
         return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
     else
         return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+
+// compile-time loop: f(IC<0>{}), ..., f(IC<N - 1>{})
+template <int I>
+using IC = std::integral_constant<int, I>;
+
+template <int... I, class Fn>
+__device__ __forceinline__ void static_for_impl(std::integer_sequence<int, I...>, Fn&& f) {
+    (f(IC<I>{}), ...);
+}
+template <int N, class Fn>
+__device__ __forceinline__ void static_for(Fn&& f) {
+    static_for_impl(std::make_integer_sequence<int, N>{}, f);
 }
 
 }  // namespace asrfe

@@ -59,18 +59,6 @@ constexpr int kPieceBytes = 16384;
 constexpr int kFfnRing = 8 * kPieceBytes;  // 128 KiB; the fp32 b1, b2 and b_o vectors follow it
 constexpr int kSlabFloats = 4096;          // four wave-private 4 KiB output slabs
 
-template <int I>
-using IC = std::integral_constant<int, I>;
-
-template <int... I, class Fn>
-__device__ __forceinline__ void static_for_impl(std::integer_sequence<int, I...>, Fn&& f) {
-    (f(IC<I>{}), ...);
-}
-template <int N, class Fn>
-__device__ __forceinline__ void static_for(Fn&& f) {
-    static_for_impl(std::make_integer_sequence<int, N>{}, f);
-}
-
 // all but the N youngest vector-memory operations of this wave are done, then every wave of the workgroup meets
 template <int N>
 __device__ __forceinline__ void wait_vm_barrier() {
