@@ -53,6 +53,8 @@ namespace asrfe {
 #define ASRFE_FFN_TIMING 0
 #endif
 
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+
 constexpr int kFfnThreads = 256;
 constexpr int kFfnRows = 128;
 constexpr int kPieceBytes = 16384;
@@ -142,7 +144,6 @@ __device__ __forceinline__ u16x8 relu16(const u16x8 v) {
 
 template <bool F16>
 __device__ __forceinline__ u16x8 pack8(float a0, float a1, float a2, float a3, float a4, float a5, float a6, float a7) {
-    typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
     const u32x4 v = {pack_elem2<F16>(a0, a1), pack_elem2<F16>(a2, a3), pack_elem2<F16>(a4, a5), pack_elem2<F16>(a6, a7)};
     return __builtin_bit_cast(u16x8, v);
 }
@@ -505,6 +506,17 @@ __global__ __launch_bounds__(kFfnThreads) void post_attn_kernel(const FfnParams 
         char* es = reinterpret_cast<char*>(b1s) + wave * 4096;
         const int wr_row = l31 * 128, wr_sw = l31 & 7;
         const int rd_row = lane >> 3, rd_c = lane & 7;
+        // The slab rows leave through buffer stores: a row at or past M lies beyond the descriptor's size and is
+        // dropped by the hardware, so no lane mask or branch surrounds a store, and the address is one 32-bit
+        // per-lane offset plus an immediate.
+        const __amdgpu_buffer_rsrc_t xo_rsrc = __builtin_amdgcn_make_buffer_rsrc(p.x_out, 0, no_store ? 0 : p.M * 2048, 0x00020000);
+        const __amdgpu_buffer_rsrc_t qkv_rsrc = __builtin_amdgcn_make_buffer_rsrc(p.qkv, 0, no_store ? 0 : p.M * p.ldq * 2, 0x00020000);
+        int xo_off[4], qkv_off[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            xo_off[i] = (row0 + rd_row + 8 * i) * 2048 + rd_c * 16;
+            qkv_off[i] = (row0 + rd_row + 8 * i) * (p.ldq * 2) + rd_c * 16;
+        }
         float mean = 0.0f, m2 = 0.0f, rstd;
 #pragma unroll
         for (int nt = 0; nt < 16; ++nt) {
@@ -533,9 +545,8 @@ __global__ __launch_bounds__(kFfnThreads) void post_attn_kernel(const FfnParams 
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int r = rd_row + 8 * i;
-                const float4 v = *reinterpret_cast<const float4*>(es + r * 128 + ((rd_c ^ (r & 7)) << 4));
-                const int m = row0 + r;
-                if (m < p.M && !no_store) *reinterpret_cast<float4*>(p.x_out + static_cast<int64_t>(m) * 512 + 32 * nt + rd_c * 4) = v;
+                const u32x4 v = *reinterpret_cast<const u32x4*>(es + r * 128 + ((rd_c ^ (r & 7)) << 4));
+                __builtin_amdgcn_raw_buffer_store_b128(v, xo_rsrc, xo_off[i] + 128 * nt, 0, 0);
             }
             ffn_wave_lds_sync();
 #pragma unroll
@@ -549,7 +560,6 @@ __global__ __launch_bounds__(kFfnThreads) void post_attn_kernel(const FfnParams 
             asm volatile("" : "+v"(afrag[2 * nt]), "+v"(afrag[2 * nt + 1]));
             tile_in(oacc[nt], bias_tile(0, nt));
         }
-        uint16_t* qkv = reinterpret_cast<uint16_t*>(p.qkv);
         FFN_STAMP();  // x_out stored, n(x_out) in fragments
 #pragma unroll 1
         for (int pass = 0; pass < 3; ++pass) {
@@ -576,10 +586,8 @@ __global__ __launch_bounds__(kFfnThreads) void post_attn_kernel(const FfnParams 
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
                         const int r = rd_row + 8 * i;
-                        const uint4 v = *reinterpret_cast<const uint4*>(es + r * 128 + ((rd_c ^ (r & 7)) << 4));
-                        const int m = row0 + r;
-                        if (m < p.M && !no_store)
-                            *reinterpret_cast<uint4*>(qkv + static_cast<int64_t>(m) * p.ldq + 512 * pass + 32 * (nt - 1) + rd_c * 8) = v;
+                        const u32x4 v = *reinterpret_cast<const u32x4*>(es + r * 128 + ((rd_c ^ (r & 7)) << 4));
+                        __builtin_amdgcn_raw_buffer_store_b128(v, qkv_rsrc, qkv_off[i] + 64 * (nt - 1), 1024 * pass, 0);
                     }
                     ffn_wave_lds_sync();
                 }
@@ -666,6 +674,9 @@ int32_t launch_post_attn(asrfe_ctx* ctx, const FfnParams& p, hipStream_t s) {
         return set_err(ctx, ASRFE_ERR_BAD_ARG, "post_attn: null or misaligned argument");
     if (p.qkv && (p.y || !p.bqkv || p.ldq % 8 != 0 || p.ff > kPostAttnQkvMaxFf))
         return set_err(ctx, ASRFE_ERR_BAD_ARG, "post_attn: qkv output excludes y, needs b_qkv and linear_units <= 5632");
+    // (its stores address rows by signed 32-bit byte offsets, up to one row tile past M)
+    if (p.qkv && (static_cast<int64_t>(p.M) + kFfnRows) * std::max<int64_t>(2048, 2 * static_cast<int64_t>(p.ldq)) >= (int64_t{1} << 31))
+        return set_err(ctx, ASRFE_ERR_SHAPE, "post_attn: x_out and qkv must each stay below 2 GiB per launch");
     const int out = p.qkv ? 2 : (p.y ? 1 : 0);
     const int lds = kFfnRing + std::max(p.ff, kSlabFloats) * 4 + 2 * 512 * 4 + (out == 2 ? 1536 * 4 : 0);
     const dim3 grid((p.M + kFfnRows - 1) / kFfnRows), block(kFfnThreads);
