@@ -52,6 +52,17 @@ def hbm_traffic(kernel):
     return None if k is None else k["fetch_bytes"] + k["write_bytes"]
 
 
+def mfma_pipe_busy(kernel):
+    """Matrix-pipe busy cycles over kernel cycles (SQ_VALU_MFMA_BUSY_CYCLES per SIMD / GRBM_GUI_ACTIVE per XCD) from the
+    same committed counter file; a profile-time figure, not measured in this run.  None if there is none."""
+    import glob
+    files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r*_hbm_traffic.json")))
+    if not files:
+        return None
+    k = json.load(open(files[-1])).get("mfma_pipe", {}).get(kernel)
+    return None if k is None else k["busy_frac_of_kernel_cycles"]
+
+
 def gemm_flops(m, n, k):
     return 2.0 * m * n * k
 
@@ -297,6 +308,7 @@ def main():
                 "unit": "TFLOP/s",
                 "frac": ach / MFMA_BF16_PEAK_TFLOPS,
                 "traffic": hbm_traffic("post_attn") if dom == "post_attn" else None,
+                "mfma_pipe_busy_profiled": mfma_pipe_busy("post_attn") if dom == "post_attn" else None,
                 "launch_us": 1e3 * st["ms_per_step"] / st["launches_per_step"],
                 "flop_per_launch": fl,
             }
