@@ -124,13 +124,21 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
+    # ASRFE_BENCH_REHEARSAL=1: a dry run of the multi-rank path on a box with ONE GPU (every rank on cuda:0, gloo
+    # instead of RCCL, which refuses two ranks on one device); its numbers mean nothing, it only exercises the code.
+    rehearsal = world > 1 and os.environ.get("ASRFE_BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist  # RCCL; used for the barrier and the MAX over ranks only
 
-        dist.init_process_group("nccl", device_id=dev)
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     import toolbox_for_asr_and_tts_amd as pkg
     from toolbox_for_asr_and_tts_amd.synth import bench_pcm, encoder_state_dict
@@ -162,7 +170,7 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearsal else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
         dist.barrier()
