@@ -265,6 +265,20 @@ def main():
             }
             del eng_r, pcm_r
 
+        # (3) latency of ONE 3 s clip (the shape of the reference's own CPU-runnable case, BASELINE configs[0]): eager
+        #     launches and the same step replayed from a captured HIP graph
+        eng_1 = pkg.AsrEngine(batch=1, max_samples=48000, state_dict=sd)
+        pcm_1 = torch.from_numpy(bench_pcm(1, 48000, seed=99)).to(dev)
+        lens_1 = torch.full((1,), 48000, dtype=torch.int32, device=dev)
+        t_eager = timed(lambda: eng_1.run(pcm_1, lens_1), 20)
+        g1 = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g1):
+            eng_1.run(pcm_1, lens_1)
+        t_graph = timed(g1.replay, 20)
+        result["single_clip_3s"] = {"eager_ms": 1e3 * t_eager, "graph_ms": 1e3 * t_graph,
+                                    "note": "one 3 s utterance per step (T' = 50 rows): latency, not throughput"}
+        del eng_1, g1
+
     if rank == 0 and not args.no_stages:
         # ---- per-kernel HIP-event pass (same process, same inputs, after the timed region) ----------
         torch.cuda.synchronize()
