@@ -667,6 +667,42 @@ def test_streaming_session_on_the_device_holds_what_the_reference_would_send(pkg
     assert torch.equal(an, bn) and torch.equal(a, b)
 
 
+def test_http_route_runs_the_engine_on_the_posted_clip(pkg):
+    """POST /api/v1/voice/asr with a 16-bit WAV: the encoder states behind the response are those of the engine run on
+    the clip's int16 samples (the route decodes to float / 32768 and the kernel scales back: no value changes)."""
+    import base64
+    import importlib
+    import io
+    import wave
+    from fastapi.testclient import TestClient
+    svc = importlib.import_module("toolbox_for_asr_and_tts_amd.service")
+    pcm = fo.synth_pcm("bursts", 16000 * 2, 17)
+    buf = io.BytesIO()
+    with wave.open(buf, "wb") as wf:
+        wf.setnchannels(1)
+        wf.setsampwidth(2)
+        wf.setframerate(16000)
+        wf.writeframes(pcm.tobytes())
+    cfg = pkg.default_config()
+    cfg.enc_num_blocks = 2
+    sd = so.make_state_dict(so.SanmConfig(num_blocks=2), seed=8)
+    eng = pkg.AsrEngine(batch=1, max_samples=16000 * 5, cfg=cfg, state_dict=sd)
+    want, wl = eng.run(dev(pcm[None]), dev(np.array([pcm.size], np.int32)))
+    want, wl = want.clone(), wl.clone()
+    seen = {}
+
+    def decoder(out, out_lens):
+        seen["out"], seen["lens"] = out.clone(), out_lens.clone()
+        return "ok"
+
+    client = TestClient(svc.create_app(eng, decoder))
+    r = client.post("/api/v1/voice/asr", json={"audio_data": base64.b64encode(buf.getvalue()).decode(),
+                                               "diagnosis_session_id": "t"})
+    assert r.status_code == 200 and r.json() == {"text": "ok", "success": True, "message": None, "sample_id": None}
+    t = int(wl[0])
+    assert torch.equal(seen["lens"], wl) and torch.equal(seen["out"][:, :t], want[:, :t])
+
+
 def test_attention_fsmn_kernel_vs_fp64(pkg):
     """The attention + FSMN kernel on its own (debug hook) against an fp64 evaluation of the same 16-bit inputs:
     ragged lengths, a length below the FSMN half-width, T' around the 64-key and 128-query tile edges."""

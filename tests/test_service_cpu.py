@@ -1,0 +1,83 @@
+"""The recognition route's surface (request / response schema, status codes) with a stand-in engine: no GPU needed.
+The schema fixture lists the reference's model fields as data."""
+import base64
+import importlib
+import io
+import json
+import os
+import wave
+
+import numpy as np
+import pytest
+import torch
+
+svc = importlib.import_module("toolbox_for_asr_and_tts_amd.service")
+from fastapi.testclient import TestClient  # noqa: E402
+
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden", "voice_asr_schema.json")
+
+
+class FakeEngine:
+    """Stands in for AsrEngine: records what it was given, returns zeros of the right shape."""
+    device = torch.device("cpu")
+    max_samples = 16000 * 30
+
+    def run(self, pcm, lens):
+        self.seen = (pcm.clone(), lens.clone())
+        t = max(1, (1 + (int(lens[0]) - 400) // 160 + 5) // 6) if int(lens[0]) >= 400 else 0
+        return torch.zeros(1, max(t, 1), 512), torch.tensor([t], dtype=torch.int32)
+
+
+def wav_b64(samples, rate=16000):
+    buf = io.BytesIO()
+    with wave.open(buf, "wb") as wf:
+        wf.setnchannels(1)
+        wf.setsampwidth(2)
+        wf.setframerate(rate)
+        wf.writeframes(samples.astype(np.int16).tobytes())
+    return base64.b64encode(buf.getvalue()).decode()
+
+
+def _fields(model):
+    sch = model.model_json_schema()
+    out = {}
+    for name, p in sch["properties"].items():
+        if "anyOf" in p:
+            ty = "|".join(sorted(x["type"] for x in p["anyOf"]))
+        else:
+            ty = p["type"]
+        ty = ty.replace("null|string", "string|null").replace("boolean|null", "boolean|null")
+        out[name] = [ty, name in sch.get("required", []), p.get("default")]
+    return out
+
+
+def test_models_have_the_reference_fields():
+    g = json.load(open(GOLDEN))
+    assert _fields(svc.ASRRequest) == g["ASRRequest"]
+    assert _fields(svc.ASRResponse) == g["ASRResponse"]
+
+
+def test_route_status_codes_and_payloads():
+    g = json.load(open(GOLDEN))
+    eng = FakeEngine()
+    client = TestClient(svc.create_app(eng))
+    assert client.get("/health").json() == g["health"]
+    x = (np.random.default_rng(0).normal(0, 3000, 16000)).astype(np.int16)
+    body = {"audio_data": wav_b64(x), "diagnosis_session_id": "s1", "sample_id": "k7"}
+    r = client.post("/api/v1/voice/asr", json=body)
+    assert r.status_code == 200 and r.headers["content-type"].startswith("application/json")
+    assert set(r.json()) == set(g["ASRResponse"])
+    assert r.json()["success"] is False and r.json()["text"] == "" and r.json()["sample_id"] == "k7"
+    # the engine saw the decoded float samples (int16 / 32768) and their count
+    pcm, lens = eng.seen
+    assert int(lens[0]) == 16000 and np.array_equal(pcm[0, :16000].numpy(), (x / 32768.0).astype(np.float32))
+    # with a decoder the text comes back
+    client2 = TestClient(svc.create_app(eng, decoder=lambda out, ol: f"frames={int(ol[0])}"))
+    r = client2.post("/api/v1/voice/asr", json=body)
+    assert r.json() == {"text": "frames=17", "success": True, "message": None, "sample_id": "k7"}
+    # refusals: short payload 400, missing required field 422 (pydantic, as in the reference), undecodable audio 500
+    assert client.post("/api/v1/voice/asr", json={"audio_data": "abc", "diagnosis_session_id": "s"}).status_code == 400
+    assert client.post("/api/v1/voice/asr", json={"audio_data": "a" * 200}).status_code == 422
+    assert client.post("/api/v1/voice/asr", json={"audio_data": "QUJD" * 50, "diagnosis_session_id": "s"}).status_code == 500
+    long = np.zeros(16000 * 31, np.int16)
+    assert client.post("/api/v1/voice/asr", json={"audio_data": wav_b64(long), "diagnosis_session_id": "s"}).status_code == 500

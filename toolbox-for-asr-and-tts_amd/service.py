@@ -1,0 +1,85 @@
+"""HTTP surface of the voice service's recognition route, over the GPU path of this package.
+
+Mirrors, for the one route that reaches the hot path, what a client of the reference sees:
+
+* ``POST /api/v1/voice/asr`` (/root/reference/voice-service/app/api/voice.py:52-89, mounted at
+  ``/api/v1/voice`` by app/main.py:100) with the request / response models of app/models/voice.py:6-21 (same field
+  names, types and defaults); payloads shorter than 100 characters are refused with HTTP 400 and any failure
+  inside the route becomes HTTP 500, as there;
+* ``GET /health`` -> ``{"status": "healthy", "service": "voice"}`` (app/main.py:191-193).
+
+What runs behind the route is this package: base64 WAV -> ``decode_wav_base64`` -> float32 samples in [-1, 1) ->
+``AsrEngine`` (float PCM is scaled by 32768 in the fbank kernel, as FunASR's loader does with the WAV file the
+reference hands it at voice_service.py:114: a 16-bit clip reaches the kernel with its original sample values) ->
+encoder states.  Turning encoder states into text is the decoder's job, which is not part of this package: ``create_app``
+takes it as a callable ``decoder(encoder_out [1, T', 512], lengths [1]) -> str``; without one the route answers
+``success = false`` with a message saying so.  Wake-word, LLM post-correction and sample saving are accepted in the
+request and ignored (they belong to the reference's control plane)."""
+from __future__ import annotations
+
+from typing import Callable, Optional
+
+import torch
+from fastapi import FastAPI, HTTPException
+from fastapi.responses import JSONResponse
+from pydantic import BaseModel
+
+from .ingress import decode_wav_base64
+
+
+class ASRRequest(BaseModel):
+    audio_data: str
+    use_wake: Optional[bool] = None
+    use_llm: Optional[bool] = None
+    save_sample: bool = False
+    sample_id: Optional[str] = None
+    diagnosis_session_id: str
+
+
+class ASRResponse(BaseModel):
+    text: str
+    success: bool
+    message: Optional[str] = None
+    sample_id: Optional[str] = None
+
+
+def recognize(engine, request: ASRRequest, decoder: Optional[Callable] = None) -> ASRResponse:
+    """One clip through the engine (batch 1).  Clips longer than the engine's ``max_samples`` are refused."""
+    samples, _ = decode_wav_base64(request.audio_data)
+    n = int(samples.shape[0])
+    if n > engine.max_samples:
+        raise ValueError(f"clip of {n} samples exceeds the engine's {engine.max_samples}")
+    pcm = torch.zeros((1, max(n, 8)), dtype=torch.float32)
+    pcm[0, :n] = torch.from_numpy(samples)
+    pcm = pcm.to(engine.device)
+    lens = torch.tensor([n], dtype=torch.int32, device=engine.device)
+    out, out_lens = engine.run(pcm, lens)
+    if decoder is None:
+        return ASRResponse(text="", success=False, sample_id=request.sample_id,
+                           message=f"encoder states computed ({int(out_lens[0])} frames); no decoder is configured")
+    text = decoder(out, out_lens)
+    return ASRResponse(text=text, success=True, message=None, sample_id=request.sample_id)
+
+
+def create_app(engine, decoder: Optional[Callable] = None) -> FastAPI:
+    """``engine``: an ``AsrEngine(batch=1, max_samples=...)`` (anything with ``run``, ``device`` and
+    ``max_samples`` serves, which is how the CPU tests drive the route)."""
+    app = FastAPI(title="voice")
+
+    @app.get("/health")
+    async def health_check():
+        return {"status": "healthy", "service": "voice"}
+
+    @app.post("/api/v1/voice/asr", response_model=ASRResponse)
+    async def speech_recognition(request: ASRRequest):
+        try:
+            if not request.audio_data or len(request.audio_data) < 100:
+                raise HTTPException(status_code=400, detail="audio data missing or too short")
+            result = recognize(engine, request, decoder)
+            return JSONResponse(content=result.model_dump(), headers={"Content-Type": "application/json; charset=utf-8"})
+        except HTTPException:
+            raise
+        except Exception as e:  # same mapping as the reference route: every failure inside is a 500
+            raise HTTPException(status_code=500, detail=f"speech recognition failed: {e}") from e
+
+    return app
