@@ -63,6 +63,16 @@ def mfma_pipe_busy(kernel):
     return None if k is None else k["busy_frac_of_kernel_cycles"]
 
 
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
 def gemm_flops(m, n, k):
     return 2.0 * m * n * k
 
@@ -93,6 +103,7 @@ def cpu_baseline(sd, n_clips: int, batch: int = 8):
         "value": n_clips / (t_front + t_enc),
         "unit": "utt/s",
         "cores": int(torch.get_num_threads()),
+        "cpu_model": cpu_model(),
         "kind": "port",
         "sample": f"{n_clips} x 30 s utterances ({batch} per call) through oracle/fbank_oracle.py (numpy f64, 1 thread) "
                   f"and oracle/sanm_oracle.py (torch fp32, {torch.get_num_threads()} threads), 50 blocks",

@@ -80,6 +80,22 @@ def test_shard_range_partitions(pkg):
         pkg.shard_range(4, 4, 4)
 
 
+def test_shard_by_length_balances_ragged_batches(pkg):
+    rng = np.random.default_rng(3)
+    lens = rng.integers(16000 * 5, 16000 * 30, 512).tolist()
+    for w in (1, 2, 4, 8):
+        parts = [pkg.shard_by_length(lens, r, w) for r in range(w)]
+        assert sorted(i for p in parts for i in p) == list(range(512))      # a partition
+        assert max(len(p) for p in parts) - min(len(p) for p in parts) <= 1
+        audio = [sum(lens[i] for i in p) for p in parts]
+        assert max(audio) - min(audio) <= 0.01 * max(audio)                 # within 1 % of each other
+        for p in parts:                                                     # each rank's clips come sorted by length
+            assert [lens[i] for i in p] == sorted(lens[i] for i in p)
+    assert pkg.shard_by_length([], 0, 2) == []
+    with pytest.raises(ValueError):
+        pkg.shard_by_length(lens, 2, 2)
+
+
 def test_missing_library_fails_loudly(pkg, monkeypatch):
     monkeypatch.setattr(pkg._lib, "_lib", None)
     monkeypatch.setattr(pkg._lib, "LIB_PATH", "/nonexistent/libasrfe.so")

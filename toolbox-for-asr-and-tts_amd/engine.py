@@ -34,6 +34,24 @@ def shard_range(n_items: int, rank: int, world_size: int):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
+def shard_by_length(host_lens, rank: int, world_size: int):
+    """Indices of the clips rank ``rank`` takes when a ragged batch is split over ``world_size`` ranks: the clips are
+    ordered by length and dealt out in a serpentine (0 1 .. w-1, w-1 .. 1 0, ..), so every rank gets the same number of
+    clips (+-1), nearly the same amount of audio and the same spread of lengths for its own length buckets.  A host-side
+    decision; nothing is exchanged between ranks (the reference's pipeline sorts by length before batching,
+    voice_interface.py:2049-2053)."""
+    if world_size < 1 or not (0 <= rank < world_size):
+        raise ValueError("shard_by_length: bad rank / world_size")
+    order = sorted(range(len(host_lens)), key=lambda i: (int(host_lens[i]), i))
+    mine = []
+    for pos, idx in enumerate(order):
+        lap, k = divmod(pos, world_size)
+        owner = k if lap % 2 == 0 else world_size - 1 - k
+        if owner == rank:
+            mine.append(idx)
+    return mine
+
+
 class AsrEngine:
     """``n_streams`` > 1 splits the batch into that many contiguous chunks, each with its own buffers and HIP
     stream: the kernels of different chunks overlap on the GPU (one chunk's memory-bound phases run beside
