@@ -703,6 +703,67 @@ def test_http_route_runs_the_engine_on_the_posted_clip(pkg):
     assert torch.equal(seen["lens"], wl) and torch.equal(seen["out"][:, :t], want[:, :t])
 
 
+@pytest.mark.timeout(90)
+def test_websocket_session_finalizes_through_the_engine(pkg):
+    """Chunks over the WebSocket route -> session policy -> (2 s of silence) -> the utterance held on the device runs
+    through an engine built with session_float: the encoder states the decoder hook receives equal those of the engine
+    run on the oracle's int16 hand-off of the oracle session's buffer."""
+    import base64
+    import importlib
+    import io
+    import json
+    import wave
+    from fastapi.testclient import TestClient
+    from oracle import ingress_oracle as ing
+    svc = importlib.import_module("toolbox_for_asr_and_tts_amd.service")
+
+    def b64(x):
+        buf = io.BytesIO()
+        with wave.open(buf, "wb") as wf:
+            wf.setnchannels(1)
+            wf.setsampwidth(2)
+            wf.setframerate(16000)
+            wf.writeframes(x.tobytes())
+        return base64.b64encode(buf.getvalue()).decode()
+
+    cfg = pkg.default_config()
+    cfg.enc_num_blocks = 2
+    sd = so.make_state_dict(so.SanmConfig(num_blocks=2), seed=9)
+    eng = pkg.AsrEngine(batch=1, max_samples=16000 * 10, cfg=cfg, state_dict=sd, session_float=True)
+    seen = {}
+
+    def decoder(out, out_lens):
+        seen["out"], seen["lens"] = out.clone(), out_lens.clone()
+        return "text"
+
+    t = [10.0]
+    client = TestClient(svc.create_app(eng, decoder, clock=lambda: t[0]))
+    ref = ing.SessionBuffer(now=10.0)
+    rng = np.random.default_rng(2)
+    with client.websocket_connect("/api/v1/voice/asr/ws") as ws:
+        assert ws.receive_json()["type"] == "welcome"
+        done = False
+        for lv in [20, 5000, 8000, 6000, 20, 20, 20, 20, 20, 20]:
+            t[0] += 0.4
+            x = rng.normal(0, lv, 6400).astype(np.int16)
+            want = ref.process_chunk((x / 32768.0).astype(np.float32), t[0])
+            ws.send_text(json.dumps({"wav_base64": b64(x)}))
+            if want["should_finalize"]:
+                assert ws.receive_json()["status"] == "finalizing"
+                assert ws.receive_json() == {"type": "result", "status": "completed", "text": "text", "success": True}
+                done = True
+                break
+            ws.send_text("sync")  # answered after the chunk: the shared clock may move on
+            assert ws.receive_json()["code"] == "INVALID_JSON"
+        assert done
+    wire = ing.wire_int16(ref.audio_buffer)
+    eng16 = pkg.AsrEngine(batch=1, max_samples=16000 * 10, cfg=cfg, state_dict=sd)
+    want, wl = eng16.run(dev(wire[None]), dev(np.array([wire.size], np.int32)))
+    torch.cuda.synchronize()
+    n = int(wl[0])
+    assert torch.equal(seen["lens"].cpu(), wl.cpu()) and torch.equal(seen["out"][:, :n].cpu(), want[:, :n].cpu())
+
+
 def test_attention_fsmn_kernel_vs_fp64(pkg):
     """The attention + FSMN kernel on its own (debug hook) against an fp64 evaluation of the same 16-bit inputs:
     ragged lengths, a length below the FSMN half-width, T' around the 64-key and 128-query tile edges."""

@@ -81,3 +81,52 @@ def test_route_status_codes_and_payloads():
     assert client.post("/api/v1/voice/asr", json={"audio_data": "QUJD" * 50, "diagnosis_session_id": "s"}).status_code == 500
     long = np.zeros(16000 * 31, np.int16)
     assert client.post("/api/v1/voice/asr", json={"audio_data": wav_b64(long), "diagnosis_session_id": "s"}).status_code == 500
+
+
+@pytest.mark.timeout(60)
+def test_websocket_protocol_with_a_scripted_clock():
+    """welcome -> chunks (quiet, speech, speech, then silence for 2 s) -> finalizing -> result; malformed messages get
+    the reference's error codes and leave the connection open; the engine sees the session policy's int16 hand-off."""
+    from oracle import ingress_oracle as ing
+    t = [1000.0]
+    eng = FakeEngine()
+    client = TestClient(svc.create_app(eng, decoder=lambda out, ol: f"frames={int(ol[0])}", clock=lambda: t[0]))
+    rng = np.random.default_rng(1)
+    ref = ing.SessionBuffer(now=1000.0)
+    with client.websocket_connect("/api/v1/voice/asr/ws") as ws:
+        w = ws.receive_json()
+        assert w["type"] == "welcome" and w["message"] == "Connected to voice recognition service"
+        assert w["mode"] == "ASR_ACTIVE" and w["use_wake"] is False and w["timestamp"] == 1000.0
+        ws.send_text("not json")
+        assert ws.receive_json()["code"] == "INVALID_JSON"
+        ws.send_text(json.dumps({"type": "audio"}))
+        assert ws.receive_json()["code"] == "MISSING_AUDIO_DATA"
+        ws.send_text(json.dumps({"wav_base64": "QUJDRA=="}))
+        assert ws.receive_json()["code"] == "AUDIO_DECODE_ERROR"
+        levels = [30, 40, 6000, 7000, 30, 30, 30, 30, 30, 30]
+        for i, lv in enumerate(levels):
+            t[0] += 0.4
+            x = rng.normal(0, lv, 6400).astype(np.int16)
+            want = ref.process_chunk((x / 32768.0).astype(np.float32), t[0])
+            key = "wav_base64" if i % 2 else "audio_data"
+            ws.send_text(json.dumps({key: wav_b64(x), "type": "audio"}))
+            if want["should_finalize"]:
+                assert ws.receive_json() == {"type": "processing", "status": "finalizing", "message": "processing audio"}
+                r = ws.receive_json()
+                assert r["type"] == "result" and r["status"] == "completed" and r["success"] is True
+                n = len(ref.audio_buffer)
+                assert r["text"] == f"frames={(1 + (n - 400) // 160 + 5) // 6}"
+                pcm, lens = eng.seen
+                assert int(lens[0]) == n and np.array_equal(pcm[0].numpy(), ing.wire_int16(ref.audio_buffer))
+                break
+            # the handler runs in another thread and reads the shared clock when it gets to the chunk: wait until it
+            # has (messages are answered in order) before the clock moves on
+            ws.send_text("sync")
+            assert ws.receive_json()["code"] == "INVALID_JSON"
+        else:
+            raise AssertionError("the session never asked to finalize")
+        # the session starts over: a silent chunk produces no message, the next malformed one is still answered
+        t[0] += 0.4
+        ws.send_text(json.dumps({"wav_base64": wav_b64(np.zeros(6400, np.int16))}))
+        ws.send_text("")
+        assert ws.receive_json()["code"] in ("EMPTY_MESSAGE", "INVALID_JSON")

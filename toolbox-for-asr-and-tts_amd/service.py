@@ -6,7 +6,15 @@ Mirrors, for the one route that reaches the hot path, what a client of the refer
   ``/api/v1/voice`` by app/main.py:100) with the request / response models of app/models/voice.py:6-21 (same field
   names, types and defaults); payloads shorter than 100 characters are refused with HTTP 400 and any failure
   inside the route becomes HTTP 500, as there;
-* ``GET /health`` -> ``{"status": "healthy", "service": "voice"}`` (app/main.py:191-193).
+* ``GET /health`` -> ``{"status": "healthy", "service": "voice"}`` (app/main.py:191-193);
+* ``WS /api/v1/voice/asr/ws`` (app/api/voice.py:92-910), the recognition part of its protocol with wake-word mode
+  off: a welcome message on connect; every client message is JSON carrying a base64 WAV chunk in ``wav_base64`` or
+  ``audio_data``; chunks go through ``StreamingPcmSession`` (the reference session's accumulation policy); when the
+  session asks to finalize, ``{"type": "processing", "status": "finalizing"}`` is sent, the utterance held on the
+  device runs through the engine and the decoder, and ``{"type": "result", "status": "completed", "text", "success"}``
+  follows; malformed input is answered with ``{"type": "error", "message", "code"}`` using the reference's codes
+  (EMPTY_MESSAGE, INVALID_JSON, MISSING_AUDIO_DATA, AUDIO_DECODE_ERROR, PROCESSING_ERROR) and the connection stays
+  open.  Wake-word activation, speaker enrolment / verification and LLM correction messages are not served.
 
 What runs behind the route is this package: base64 WAV -> ``decode_wav_base64`` -> float32 samples in [-1, 1) ->
 ``AsrEngine`` (float PCM is scaled by 32768 in the fbank kernel, as FunASR's loader does with the WAV file the
@@ -20,11 +28,11 @@ from __future__ import annotations
 from typing import Callable, Optional
 
 import torch
-from fastapi import FastAPI, HTTPException
+from fastapi import FastAPI, HTTPException, WebSocket, WebSocketDisconnect
 from fastapi.responses import JSONResponse
 from pydantic import BaseModel
 
-from .ingress import decode_wav_base64
+from .ingress import StreamingPcmSession, decode_wav_base64
 
 
 class ASRRequest(BaseModel):
@@ -61,8 +69,28 @@ def recognize(engine, request: ASRRequest, decoder: Optional[Callable] = None) -
     return ASRResponse(text=text, success=True, message=None, sample_id=request.sample_id)
 
 
-def create_app(engine, decoder: Optional[Callable] = None) -> FastAPI:
-    """``engine``: an ``AsrEngine(batch=1, max_samples=...)`` (anything with ``run``, ``device`` and
+def finalize_session(engine, session: StreamingPcmSession, decoder: Optional[Callable] = None) -> str:
+    """What the reference session's ``finalize`` hands to its pipeline, run here: the utterance the session holds ->
+    encoder states -> ``decoder`` -> text ("" without a decoder or without audio).  An engine built with
+    ``session_float=True`` takes the float buffer as it is (the int16 hand-off happens in the kernel's load);
+    any other engine gets the int16 hand-off itself.  Same bits either way."""
+    n = len(session.audio)
+    if n == 0 or decoder is None:
+        return ""
+    if n > engine.max_samples:
+        raise ValueError(f"utterance of {n} samples exceeds the engine's {engine.max_samples}")
+    if getattr(engine, "session_float", False):
+        pcm = session.samples().reshape(1, -1)
+        lens = torch.tensor([n], dtype=torch.int32, device=engine.device)
+    else:
+        pcm, lens = session.wire()
+    out, out_lens = engine.run(pcm.to(engine.device), lens.to(engine.device))
+    return decoder(out, out_lens) or ""
+
+
+def create_app(engine, decoder: Optional[Callable] = None, clock: Optional[Callable[[], float]] = None) -> FastAPI:
+    """``clock``: the time source of the streaming sessions' silence timer (``time.time`` by default).
+    ``engine``: an ``AsrEngine(batch=1, max_samples=...)`` (anything with ``run``, ``device`` and
     ``max_samples`` serves, which is how the CPU tests drive the route)."""
     app = FastAPI(title="voice")
 
@@ -81,5 +109,62 @@ def create_app(engine, decoder: Optional[Callable] = None) -> FastAPI:
             raise
         except Exception as e:  # same mapping as the reference route: every failure inside is a 500
             raise HTTPException(status_code=500, detail=f"speech recognition failed: {e}") from e
+
+    @app.websocket("/api/v1/voice/asr/ws")
+    async def speech_recognition_websocket(websocket: WebSocket):
+        import json
+        import time
+        now = clock or time.time
+        await websocket.accept()
+        try:
+            session = StreamingPcmSession(device=engine.device, now=now())
+        except Exception as e:
+            await websocket.send_json({"type": "error", "message": f"session creation failed: {e}",
+                                       "code": "SESSION_CREATE_ERROR"})
+            await websocket.close(code=1011, reason="Failed to create session")
+            return
+        await websocket.send_json({"type": "welcome", "message": "Connected to voice recognition service",
+                                   "timestamp": now(), "use_wake": False, "mode": "ASR_ACTIVE"})
+        while True:
+            try:
+                text = await websocket.receive_text()
+                if not text:
+                    await websocket.send_json({"type": "error", "message": "empty message ignored", "code": "EMPTY_MESSAGE"})
+                    continue
+                try:
+                    data = json.loads(text)
+                except json.JSONDecodeError:
+                    await websocket.send_json({"type": "error", "message": "messages must be JSON", "code": "INVALID_JSON"})
+                    continue
+                wav_b64 = (data.get("wav_base64") or data.get("audio_data")) if isinstance(data, dict) else None
+                if not wav_b64 or not isinstance(wav_b64, str):
+                    await websocket.send_json({"type": "error", "message": "field 'wav_base64' or 'audio_data' missing",
+                                               "code": "MISSING_AUDIO_DATA"})
+                    continue
+                try:
+                    chunk, _ = decode_wav_base64(wav_b64)
+                except Exception as e:
+                    await websocket.send_json({"type": "error", "message": f"audio decoding failed: {e}",
+                                               "code": "AUDIO_DECODE_ERROR"})
+                    continue
+                try:
+                    state = session.process_chunk(chunk, now())
+                    if state["should_finalize"]:
+                        await websocket.send_json({"type": "processing", "status": "finalizing",
+                                                   "message": "processing audio"})
+                        final_text = finalize_session(engine, session, decoder)
+                        if final_text:
+                            await websocket.send_json({"type": "result", "status": "completed", "text": final_text,
+                                                       "success": True})
+                        else:
+                            await websocket.send_json({"type": "result", "status": "completed", "text": "",
+                                                       "success": False, "message": "nothing recognised, please repeat"})
+                        session.reset(now())
+                except Exception as e:
+                    await websocket.send_json({"type": "error", "message": f"chunk processing failed: {e}",
+                                               "code": "PROCESSING_ERROR"})
+                    continue
+            except WebSocketDisconnect:
+                break
 
     return app
