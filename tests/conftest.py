@@ -12,6 +12,10 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # no test here needs minutes: a run without --timeout must still end if something blocks (a socket, a GPU call)
+    if config.pluginmanager.hasplugin("timeout") and not getattr(config.option, "timeout", None):
+        config.option.timeout = 300
+        config.option.timeout_method = "thread"
 
 
 def _has_gpu():
