@@ -177,7 +177,7 @@ def test_fbank_full_size_properties(fe):
     assert torch.equal(feats, gathered)
 
 
-@pytest.mark.parametrize("n_mels,lfr_m,lfr_n", [(40, 5, 3), (64, 1, 1), (32, 7, 6)])
+@pytest.mark.parametrize("n_mels,lfr_m,lfr_n", [(40, 5, 3), (64, 1, 1), (32, 7, 6), (80, 5, 1)])  # the last: fsmn-vad's frontend
 def test_fbank_other_mel_layouts(pkg, n_mels, lfr_m, lfr_n):
     """Filter counts other than 80 go through the kernel's run-time mel loops (the 80-filter layout has its trip
     counts compiled in) and other LFR shapes through the scatter: log-mel and features against the oracle."""
