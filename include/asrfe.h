@@ -61,6 +61,12 @@ extern "C" {
 #define ASRFE_DT_BF16 1
 #define ASRFE_DT_F16 2
 
+/* Threading.  A context is immutable once its tables and weights are loaded: asrfe_fbank, asrfe_lfr_cmvn,
+ * asrfe_frontend and asrfe_encoder_forward only enqueue kernels on the caller's stream and may be called from
+ * several threads at once on one context, provided every call has its own outputs and workspace.  The last-error
+ * text is kept per context, not per thread (read it right after the failing call, or serialise the callers), and
+ * asrfe_load_*, asrfe_profile_* and asrfe_destroy must not run beside other calls on the same context.  The
+ * reference calls its models synchronously from one thread (voice-service/app/api/voice.py:613). */
 typedef struct asrfe_ctx asrfe_ctx;
 
 /* Frontend + encoder hyper-parameters (FunASR config.yaml: frontend_conf / encoder_conf). */
