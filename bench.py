@@ -346,6 +346,26 @@ def main():
                 "flop_per_launch": fl,
             }
 
+        if "attention" in stages:
+            st = stages["attention"]
+            fl = flops["attention"] / 50
+            us = 1e3 * st["ms_per_step"] / st["launches_per_step"]
+            tr = hbm_traffic("attention")
+            result["roofline_attention"] = {
+                "kernel": "attn_kernel<f16> (64 x 4 heads x 500 x 500 x 128: Q K^T, online softmax, P V, then the FSMN "
+                          "memory block of the same rows)",
+                "bound": "mfma",
+                "achieved": fl / (us * 1e-6) / 1e12,
+                "peak": MFMA_BF16_PEAK_TFLOPS,
+                "unit": "TFLOP/s",
+                "frac": fl / (us * 1e-6) / 1e12 / MFMA_BF16_PEAK_TFLOPS,
+                "traffic": tr,
+                "hbm_gbps_from_traffic": None if tr is None else tr / (us * 1e-6) / 1e9,
+                "mfma_pipe_busy_profiled": mfma_pipe_busy("attention"),
+                "launch_us": us,
+                "flop_per_launch": fl,
+            }
+
         # ---- fbank-only stage: 256 x 30 s -> 80-dim log-mel (HBM roofline) ---------------------------
         fb = args.fbank_batch
         del pcm
