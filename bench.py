@@ -5,12 +5,17 @@
 
 A step is one pass of frontend + encoder over one batch of 64 synthetic 30 s utterances per GPU (the
 per-GPU slice of BASELINE.json's "batch 512 sharded 64/GPU" configuration; inputs are resident in HBM
-before the timed region).  For N > 1 the launcher starts one rank per GPU; utterances are independent,
-so ranks exchange nothing on the data path: only a barrier and a MAX over ranks of the elapsed time.
+before the timed region).  Utterances are independent, so ranks exchange nothing on the data path: only a
+barrier and a MAX over ranks of the elapsed time (RCCL).  N > 1 runs either under a launcher that sets
+RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* (python -m torch.distributed.run ...), or plainly as
+``python bench.py --gpus N``: the process then starts N children of itself, one per GPU, before it touches
+the GPU, relays rank 0's JSON line and fails if a child fails or fewer than N devices are visible.
+``--scaling strong`` keeps the global batch fixed (--global-batch, default 512) and splits it over the ranks.
 
 Rank 0 prints ONE JSON line.  Besides the contract fields it carries
-  roofline      : the dominant kernel (FFN1 GEMM, bf16 MFMA) priced against the dense bf16 MFMA peak from
-                  HIP-event timings taken inside this process,
+  roofline      : the dominant kernel (post_attn_kernel: everything of a layer behind attention, fp16 MFMA
+                  operands) priced against the dense 16-bit MFMA peak from HIP-event timings taken inside
+                  this process,
   roofline_fbank: the fbank kernel on 256 x 30 s (BASELINE.json configs[1]) priced against HBM peak,
   cpu_baseline  : the CPU oracle (a port: the reference's own CPU stack is not installable offline)
                   timed on a bounded sample on this host's cores,
@@ -41,25 +46,45 @@ GEMM_FLOP_PER_UTT = 157.4e9             # QKV + out-proj + FFN over 50 layers at
 ALL_FLOP_PER_UTT = 183.2e9              # + attention matmuls + FSMN
 
 
+_COUNTERS = None
+
+
+def counter_profile():
+    """The newest committed counter pass (profiles/r*_hbm_traffic.json; the counters need rocprofv3 runs of their own,
+    so they cannot be taken inside this process) IF it was taken with the kernel sources this tree holds: the file
+    records a hash of csrc/ (tools/buildtag.py) and a file of another build is not quoted.  Returns (data or None,
+    source record for the JSON line)."""
+    global _COUNTERS
+    if _COUNTERS is None:
+        import glob
+        from tools.buildtag import csrc_tag
+        files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_hbm_traffic.json")))
+        src = {"file": None, "build": None, "csrc_tag": None, "this_build_csrc_tag": csrc_tag(), "used": False}
+        data = None
+        if files:
+            d = json.load(open(files[-1]))
+            src.update(file=os.path.relpath(files[-1], ROOT), build=d.get("build"), csrc_tag=d.get("csrc_tag"))
+            if d.get("csrc_tag") == src["this_build_csrc_tag"]:
+                data, src["used"] = d, True
+            else:
+                src["note"] = "counter file belongs to another build of the kernels: not quoted"
+        _COUNTERS = (data, src)
+    return _COUNTERS
+
+
 def hbm_traffic(kernel):
-    """HBM bytes per launch of a kernel from the newest committed counter pass (profiles/r*_hbm_traffic.json: the
-    counters need rocprofv3 runs of their own, so they cannot be taken inside this process); None if there is none."""
-    import glob
-    files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r*_hbm_traffic.json")))
-    if not files:
-        return None
-    k = json.load(open(files[-1])).get("kernels", {}).get(kernel)
+    """HBM bytes per launch of a kernel (FETCH_SIZE corrected + WRITE_SIZE) from the committed counter pass of this
+    build; None if there is none."""
+    d, _ = counter_profile()
+    k = None if d is None else d.get("kernels", {}).get(kernel)
     return None if k is None else k["fetch_bytes"] + k["write_bytes"]
 
 
 def mfma_pipe_busy(kernel):
     """Matrix-pipe busy cycles over kernel cycles (SQ_VALU_MFMA_BUSY_CYCLES per SIMD / GRBM_GUI_ACTIVE per XCD) from the
-    same committed counter file; a profile-time figure, not measured in this run.  None if there is none."""
-    import glob
-    files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r*_hbm_traffic.json")))
-    if not files:
-        return None
-    k = json.load(open(files[-1])).get("mfma_pipe", {}).get(kernel)
+    same file; a profile-time figure, not measured in this run.  None if there is none."""
+    d, _ = counter_profile()
+    k = None if d is None else d.get("mfma_pipe", {}).get(kernel)
     return None if k is None else k["busy_frac_of_kernel_cycles"]
 
 
@@ -99,10 +124,24 @@ def cpu_baseline(sd, n_clips: int, batch: int = 8):
         t_front += t1 - t0
         t_enc += t2 - t1
         done += b
+    # one thread: a single clip through the same chain
+    nthr = torch.get_num_threads()
+    torch.set_num_threads(1)
+    try:
+        pcm1 = bench_pcm(1, SAMPLES, seed=7)
+        t0 = time.perf_counter()
+        f1, l1 = fo.frontend(pcm1, [SAMPLES])
+        with torch.no_grad():
+            so.encoder_forward(torch.from_numpy(f1).float(), torch.from_numpy(l1), sd, cfg)
+        t_one = time.perf_counter() - t0
+    finally:
+        torch.set_num_threads(nthr)
     return {
         "value": n_clips / (t_front + t_enc),
+        "one_thread_value": 1.0 / t_one,
         "unit": "utt/s",
         "cores": int(torch.get_num_threads()),
+        "host_cpus": os.cpu_count(),
         "cpu_model": cpu_model(),
         "kind": "port",
         "sample": f"{n_clips} x 30 s utterances ({batch} per call) through oracle/fbank_oracle.py (numpy f64, 1 thread) "
@@ -110,6 +149,37 @@ def cpu_baseline(sd, n_clips: int, batch: int = 8):
         "frontend_s": t_front,
         "encoder_s": t_enc,
     }
+
+
+def launch_ranks(n: int) -> int:
+    """``python bench.py --gpus N`` without a launcher: start N copies of this script, one rank per GPU, relay rank 0's
+    output and return non-zero if any rank fails.  Runs BEFORE this process makes any GPU call (counting devices does
+    not initialise the GPU) and starts fresh child processes: a process that has touched the GPU is never replaced."""
+    import socket
+    import subprocess
+
+    rehearsal = os.environ.get("ASRFE_BENCH_REHEARSAL") == "1"  # every rank on cuda:0 of a one-GPU box (gloo)
+    n_dev = torch.cuda.device_count()
+    if n_dev < n and not rehearsal:
+        print(f"bench.py: --gpus {n} but only {n_dev} GPU(s) are visible", file=sys.stderr)
+        return 2
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    for r, p in enumerate(procs):
+        code = p.wait()
+        if code != 0:
+            print(f"bench.py: rank {r} exited with status {code}", file=sys.stderr)
+            rc = rc or (code if 0 < code < 256 else 1)
+    return rc
 
 
 def main():
@@ -126,13 +196,27 @@ def main():
     ap.add_argument("--graph", type=int, default=0, help="1: replay the step from a captured HIP graph")
     ap.add_argument("--buckets", type=int, default=4, help="length buckets of the ragged side run (0: skip it)")
     ap.add_argument("--no-extras", action="store_true", help="skip the ragged and host-copy side runs")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
+                    help="weak: --batch utterances per GPU; strong: --global-batch utterances split over the GPUs")
+    ap.add_argument("--global-batch", type=int, default=512, help="utterances per step over all GPUs (strong scaling)")
     args = ap.parse_args()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        raise SystemExit(launch_ranks(args.gpus))  # this process never touches the GPU
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: a measurement of {world} rank(s) would be "
+                         f"reported as one of {args.gpus}")
+    if args.scaling == "strong":
+        from toolbox_for_asr_and_tts_amd.engine import shard_range
+        lo, hi = shard_range(args.global_batch, rank, world)
+        args.batch = hi - lo
+        if args.batch < 1:
+            raise SystemExit("--global-batch must give every rank at least one utterance")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
     # ASRFE_BENCH_REHEARSAL=1: a dry run of the multi-rank path on a box with ONE GPU (every rank on cuda:0, gloo
@@ -180,41 +264,54 @@ def main():
         step()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    ranks_seen = 1
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearsal else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+        ones = torch.ones(1, dtype=torch.int32, device="cpu" if rehearsal else dev)
+        dist.all_reduce(ones, op=dist.ReduceOp.SUM)  # every rank that took part in the timed region counts itself
+        ranks_seen = int(ones.item())
+        counts = torch.tensor([args.batch], dtype=torch.int64, device="cpu" if rehearsal else dev)
+        dist.all_reduce(counts, op=dist.ReduceOp.SUM)
+        global_batch = int(counts.item())
         dist.barrier()
+    else:
+        global_batch = args.batch
     out_ok = bool(torch.isfinite(eng.out).all().item())
 
     result = None
     if rank == 0:
-        utts = world * args.batch * args.steps
+        utts = global_batch * args.steps
         value = utts / elapsed
         result = {
             "metric": "utterances/sec (30 s @16 kHz) fbank+Paraformer encoder",
             "value": value,
             "unit": "utt/s",
             "n_gpus": world,
+            "ranks_seen": ranks_seen,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": args.scaling,
             "vs_baseline": None,
             "dtype": "f16",
             "data": "synthetic",
             "config": {
                 "workload": f"fbank+LFR+CMVN+SAN-M encoder (50 blocks, d=512), {args.batch} x 30 s int16 utterances "
                             f"per GPU per step (BASELINE configs[3] slice: 64/GPU), random-init N(0,0.02) weights",
-                "batch_per_gpu": args.batch,
-                "global_batch": world * args.batch,
+                "batch_per_gpu": args.batch if args.scaling == "weak" else f"{global_batch} / {world}",
+                "global_batch": global_batch,
                 "parallelism": f"utterance-sharded x{world}, no collective",
                 "streams_per_gpu": args.streams,
             },
             "output_finite": out_ok,
             "achieved_tflops_all": value * ALL_FLOP_PER_UTT / 1e12 / world,
+            "counter_profile": counter_profile()[1],
         }
+        if ranks_seen != world:
+            raise SystemExit(f"{ranks_seen} rank(s) answered the all-reduce, {world} expected")
 
     if rank == 0 and world == 1 and not args.no_extras:
         # ---- side runs, reported beside the headline number and never part of it --------------------------
@@ -275,6 +372,17 @@ def main():
                 "buckets": args.buckets,
             }
             del eng_r, pcm_r
+
+        # (2b) the same step with bf16 MFMA operands (the operand type BASELINE.json's encoder configuration names; the
+        #      default here is fp16 because bf16 rounding alone exceeds the 1e-2 parity bar): same kernels, same rate
+        from toolbox_for_asr_and_tts_amd import _lib as _l
+        cfg_b = pkg.default_config()
+        cfg_b.enc_compute_dtype = _l.DT_BF16
+        eng_b = pkg.AsrEngine(batch=args.batch, max_samples=SAMPLES, cfg=cfg_b, state_dict=sd, n_streams=args.streams)
+        t_b = timed(lambda: eng_b.run(pcm, lens), args.steps)
+        result["dtype_alt"] = {"bf16": {"utt_per_s": args.batch / t_b, "ms_per_step": 1e3 * t_b,
+                                        "note": "enc_compute_dtype = ASRFE_DT_BF16, same step; parity 6e-2 instead of 1e-2"}}
+        del eng_b
 
         # (3) latency of ONE 3 s clip (the shape of the reference's own CPU-runnable case, BASELINE configs[0]): eager
         #     launches and the same step replayed from a captured HIP graph

@@ -49,6 +49,7 @@ extern "C" {
 #define ASRFE_ERR_UNSUPPORTED_ARCH (-4)
 #define ASRFE_ERR_NOT_LOADED (-5)
 #define ASRFE_ERR_WORKSPACE (-6)
+#define ASRFE_ERR_RANGE (-7) /* fp16 operands cannot hold this model's activations: use ASRFE_DT_BF16 */
 
 #define ASRFE_PCM_I16 0
 #define ASRFE_PCM_F32 1
@@ -64,8 +65,9 @@ extern "C" {
 /* Threading.  A context is immutable once its tables and weights are loaded: asrfe_fbank, asrfe_lfr_cmvn,
  * asrfe_frontend and asrfe_encoder_forward only enqueue kernels on the caller's stream and may be called from
  * several threads at once on one context, provided every call has its own outputs and workspace.  The last-error
- * text is kept per context, not per thread (read it right after the failing call, or serialise the callers), and
- * asrfe_load_*, asrfe_profile_* and asrfe_destroy must not run beside other calls on the same context.  The
+ * text is kept per thread: asrfe_last_error(ctx) returns the text of the calling thread's last failed call on ctx.
+ * asrfe_load_*, asrfe_profile_* and asrfe_destroy must not run beside other calls on the same context
+ * (asrfe_load_cmvn waits for the device to go idle before it replaces the table).  The
  * reference calls its models synchronously from one thread (voice-service/app/api/voice.py:613). */
 typedef struct asrfe_ctx asrfe_ctx;
 
@@ -114,7 +116,13 @@ int32_t asrfe_destroy(asrfe_ctx* ctx);
 /* am.mvn of the model directory: y = (x + shift) * scale over lfr_m * n_mels dims (host pointers). */
 int32_t asrfe_load_cmvn(asrfe_ctx* ctx, const float* shift_host, const float* scale_host, int32_t dim);
 
-/* model.pt encoder tensors (host float32); converted to the device layout the kernels use. */
+/* model.pt encoder tensors (host float32); converted to the device layout the kernels use.
+ * With ASRFE_DT_F16 operands the call first proves that no activation the kernels round to fp16 can leave the fp16
+ * range: q, k, v, the attention output, the FSMN memory and the feed-forward hidden layer are linear images of a
+ * normalised row n (||n||_2 = sqrt(K)), so |w . n + c| <= ||w||_2 sqrt(K) + |c| bounds them from the weights alone.
+ * Weights that fail the bound are refused with ASRFE_ERR_RANGE (load them into a context created with
+ * ASRFE_DT_BF16); ordinary checkpoints stay orders of magnitude below it.  Independently of the proof the kernels
+ * convert to fp16 with saturation (+-65504, never an infinity). */
 int32_t asrfe_load_encoder_weights(asrfe_ctx* ctx, const asrfe_tensor_desc* descs, int32_t n);
 
 /* snip_edges frame count and LFR frame count for a clip of n_samples (host helpers). */
@@ -122,7 +130,10 @@ int32_t asrfe_num_frames(const asrfe_ctx* ctx, int64_t n_samples);
 int32_t asrfe_num_lfr_frames(const asrfe_ctx* ctx, int32_t n_frames);
 
 /* kaldi.fbank over a batch: logmel[b, t, :] for t < n_frames[b]; rows t >= n_frames[b] (< t_max) are zero.
- * logmel: [B, t_max, n_mels] float32, n_frames_out: [B] int32 (device). */
+ * logmel: [B, t_max, n_mels] float32, n_frames_out: [B] int32 (device).
+ * Truncation: a clip with more than t_max frames is processed as if it had been cut after frame t_max - 1, and
+ * n_frames_out[b] = t_max.  asrfe_frontend does the same at tp_max * lfr_n frames (lens_out[b] <= tp_max), and
+ * asrfe_lfr_cmvn reads at most t_max frames per clip and reports at most tp_max rows. */
 int32_t asrfe_fbank(asrfe_ctx* ctx, const void* pcm, int32_t pcm_dtype, int64_t pcm_stride,
                     const int32_t* pcm_lens, int32_t batch, int32_t t_max, float* logmel,
                     int32_t* n_frames_out, void* stream);

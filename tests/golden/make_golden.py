@@ -17,6 +17,13 @@ Files written:
   fbank_<kind>_s<seed>_<n>.npz : pcm int16, logmel f32 (T, 80), feats f32 (T', 560), shift/scale f32
   encoder_tiny.npz             : 2-layer SAN-M encoder, B=2, T'=40 ragged: feats, lens, out (fp64 oracle -> f32)
   encoder_probe_50l.npz        : 50-layer encoder, B=2, T'=96 ragged: out slices + checksums
+  encoder_full_50l_t500.npz    : 50-layer encoder at the full frame count, B=2, T'=500 with lens [500, 333]
+                                 (fp64 oracle): selected rows, per-clip column sums, mean |out|
+  bench_clips_50l.npz          : clips 0, 31 and 63 of the benchmark batch (synth.bench_pcm(64, 480000, 1234), 30 s
+                                 each) through the whole oracle chain, fbank -> LFR -> CMVN (identity) -> 50 blocks in
+                                 fp64 with the benchmark's weights: selected feature rows and encoder rows, column sums
+
+``python tests/golden/make_golden.py full`` writes only the last two (several minutes of CPU time).
 """
 from __future__ import annotations
 
@@ -85,7 +92,63 @@ def synth_cmvn(seed: int):
     return shift, scale
 
 
+FULL_ROWS = [0, 1, 2, 49, 50, 127, 128, 255, 256, 332, 333, 400, 498, 499]
+BENCH_CLIPS = [0, 31, 63]
+
+
+def full_size_goldens():
+    """The two full-size encoder fixtures (50 blocks, T' = 500)."""
+    cfg = so.SanmConfig(num_blocks=50)
+    sd = so.make_state_dict(cfg, seed=0, dtype=torch.float64)
+    feats = so.synth_feats(2, 500, 560, seed=13, dtype=torch.float64)
+    lens = torch.tensor([500, 333], dtype=torch.int32)
+    out, olens = so.encoder_forward(feats, lens, sd, cfg)
+    o = out.numpy()
+    rows1 = [r for r in FULL_ROWS if r < 333]
+    np.savez_compressed(
+        os.path.join(OUT, "encoder_full_50l_t500.npz"),
+        lens=lens.numpy(),
+        rows=np.array(FULL_ROWS, np.int32),
+        rows_b0=o[0, FULL_ROWS].astype(np.float32),
+        rows1=np.array(rows1, np.int32),
+        rows_b1=o[1, rows1].astype(np.float32),
+        col_sums=o.sum(axis=1).astype(np.float64),
+        abs_mean=np.float64(np.abs(o).mean()),
+        seed=np.int32(0),
+        feats_seed=np.int32(13),
+        num_blocks=np.int32(50),
+    )
+    print("encoder full 50l t500:", tuple(out.shape), "abs mean", float(np.abs(o).mean()))
+
+    # the benchmark's own batch: three of its 64 clips through the whole chain
+    sys.path.insert(0, ROOT)
+    from toolbox_for_asr_and_tts_amd.synth import bench_pcm, encoder_state_dict
+
+    pcm = bench_pcm(64, 480000, seed=1234)[BENCH_CLIPS]
+    f, fl = fo.frontend(pcm, [480000] * len(BENCH_CLIPS))
+    sd = {k: v.double() for k, v in encoder_state_dict(num_blocks=50, seed=0).items()}
+    out, olens = so.encoder_forward(torch.from_numpy(f).double(), torch.from_numpy(fl), sd, cfg)
+    o = out.numpy()
+    np.savez_compressed(
+        os.path.join(OUT, "bench_clips_50l.npz"),
+        clips=np.array(BENCH_CLIPS, np.int32),
+        pcm_seed=np.int32(1234),
+        weights_seed=np.int32(0),
+        rows=np.array(FULL_ROWS, np.int32),
+        feat_rows=f[:, FULL_ROWS].astype(np.float32),
+        feat_col_sums=f.sum(axis=1).astype(np.float64),
+        out_rows=o[:, FULL_ROWS].astype(np.float32),
+        out_col_sums=o.sum(axis=1).astype(np.float64),
+        out_abs_mean=np.float64(np.abs(o).mean()),
+        olens=olens.numpy(),
+    )
+    print("bench clips 50l:", tuple(out.shape), "abs mean", float(np.abs(o).mean()))
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "full":
+        full_size_goldens()
+        return
     worst = 0.0
     for kind, seed, n in FBANK_CASES:
         pcm = fo.synth_pcm(kind, n, seed)

@@ -130,3 +130,38 @@ def test_websocket_protocol_with_a_scripted_clock():
         ws.send_text(json.dumps({"wav_base64": wav_b64(np.zeros(6400, np.int16))}))
         ws.send_text("")
         assert ws.receive_json()["code"] in ("EMPTY_MESSAGE", "INVALID_JSON")
+
+
+@pytest.mark.timeout(60)
+def test_websocket_recovers_after_an_utterance_the_engine_refuses():
+    """An utterance longer than the engine's max_samples fails once (PROCESSING_ERROR) and the session starts over: the
+    following silent chunks do not re-trigger the failure, and the next utterance is recognised."""
+    t = [500.0]
+    eng = FakeEngine()
+    eng.max_samples = 6400 * 3      # the first utterance (pre-speech + 3 loud + 2 silent chunks) is longer than this
+    client = TestClient(svc.create_app(eng, decoder=lambda out, ol: f"frames={int(ol[0])}", clock=lambda: t[0]))
+    rng = np.random.default_rng(3)
+
+    def send(ws, level):
+        t[0] += 0.4
+        ws.send_text(json.dumps({"wav_base64": wav_b64(rng.normal(0, level, 6400).astype(np.int16))}))
+        ws.send_text("sync")  # answered after the chunk
+        msgs = []
+        while True:
+            m = ws.receive_json()
+            if m.get("code") == "INVALID_JSON":
+                return msgs
+            msgs.append(m)
+
+    with client.websocket_connect("/api/v1/voice/asr/ws") as ws:
+        assert ws.receive_json()["type"] == "welcome"
+        got = []
+        for lv in [30, 6000, 7000, 6500] + [30] * 8:
+            got += send(ws, lv)
+        kinds = [(m["type"], m.get("code")) for m in got]
+        assert kinds == [("processing", None), ("error", "PROCESSING_ERROR")], kinds   # failed once, not on every chunk
+        eng.max_samples = 16000 * 30
+        got = []
+        for lv in [6000, 7000] + [30] * 8:
+            got += send(ws, lv)
+        assert [m["type"] for m in got] == ["processing", "result"] and got[1]["success"] is True

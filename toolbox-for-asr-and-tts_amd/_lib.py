@@ -23,6 +23,7 @@ ERROR_NAMES = {
     -4: "UNSUPPORTED_ARCH",
     -5: "NOT_LOADED",
     -6: "WORKSPACE",
+    -7: "RANGE",
 }
 
 

@@ -12,12 +12,20 @@
 
 using namespace asrfe;
 
+// The error text is kept per thread (and tagged with the context it belongs to): compute calls may run on several
+// threads of one context at once, and each reads back the text of its own failure.
 static thread_local std::string g_create_err;
+static thread_local const asrfe_ctx* g_err_ctx = nullptr;
+static thread_local std::string g_err;
 
 namespace asrfe {
 int32_t set_err(asrfe_ctx* ctx, int32_t code, const std::string& msg) {
-    if (ctx) ctx->err = msg;
-    else g_create_err = msg;
+    if (ctx) {
+        g_err_ctx = ctx;
+        g_err = msg;
+    } else {
+        g_create_err = msg;
+    }
     return code;
 }
 }  // namespace asrfe
@@ -31,7 +39,10 @@ int32_t set_err(asrfe_ctx* ctx, int32_t code, const std::string& msg) {
 
 extern "C" const char* asrfe_version(void) { return "asrfe 0.1.0 (gfx950)"; }
 
-extern "C" const char* asrfe_last_error(const asrfe_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_err.c_str(); }
+extern "C" const char* asrfe_last_error(const asrfe_ctx* ctx) {
+    if (!ctx) return g_create_err.c_str();
+    return g_err_ctx == ctx ? g_err.c_str() : "";
+}
 
 extern "C" int32_t asrfe_default_config(asrfe_config* c) {
     if (!c) return ASRFE_ERR_BAD_ARG;
@@ -180,7 +191,8 @@ extern "C" int32_t asrfe_create(const asrfe_config* cfg, asrfe_ctx** out) {
     std::memset(&ctx->tab, 0, sizeof(ctx->tab));
 
     auto fail = [&](int32_t rc) {
-        g_create_err = ctx->err;
+        g_create_err = g_err_ctx == ctx ? g_err : std::string();
+        g_err_ctx = nullptr;
         asrfe_destroy(ctx);
         return rc;
     };
@@ -226,8 +238,7 @@ extern "C" int32_t asrfe_create(const asrfe_config* cfg, asrfe_ctx** out) {
         }
     }
     if (cfg->low_freq <= 0.0f) {
-        ctx->err = "asrfe_create: low_freq must be > 0 (the DC bin is not computed)";
-        return fail(ASRFE_ERR_BAD_ARG);
+        return fail(set_err(ctx, ASRFE_ERR_BAD_ARG, "asrfe_create: low_freq must be > 0 (the DC bin is not computed)"));
     }
     int total = 0;
     for (int g = 0; g < kMelGroups; ++g) {
@@ -239,8 +250,7 @@ extern "C" int32_t asrfe_create(const asrfe_config* cfg, asrfe_ctx** out) {
         total += gw;
     }
     if (total > kMelMaxTerms) {
-        ctx->err = "asrfe_create: mel filters too wide for the kernel's table";
-        return fail(ASRFE_ERR_BAD_ARG);
+        return fail(set_err(ctx, ASRFE_ERR_BAD_ARG, "asrfe_create: mel filters too wide for the kernel's table"));
     }
     std::vector<float> mw(kMelMaxTerms * 16, 0.0f);
     std::vector<int32_t> msb(kMelGroups * 16, 1);
@@ -270,6 +280,9 @@ extern "C" int32_t asrfe_create(const asrfe_config* cfg, asrfe_ctx** out) {
     const double inc = std::log(10000.0) / (half - 1);
     for (int i = 0; i < half; ++i) inv[i] = static_cast<float>(std::exp(-inc * i));
     if ((rc = upload(ctx, inv, &ctx->pe_inv))) return fail(rc);
+
+    // per-device kernel attributes (dynamic LDS above 64 KiB), set here so that no compute call ever has to
+    if ((rc = prepare_gemm(ctx)) || (rc = prepare_post_attn(ctx))) return fail(rc);
 
     *out = ctx;
     return ASRFE_OK;
@@ -318,6 +331,8 @@ extern "C" int32_t asrfe_load_cmvn(asrfe_ctx* ctx, const float* shift, const flo
     if (!ctx || !shift || !scale) return set_err(ctx, ASRFE_ERR_BAD_ARG, "asrfe_load_cmvn: null argument");
     if (dim != ctx->cfg.lfr_m * ctx->cfg.n_mels)
         return set_err(ctx, ASRFE_ERR_SHAPE, "asrfe_load_cmvn: dim must be lfr_m * n_mels");
+    // kernels already enqueued on any stream (non-blocking ones included) read the old table to the end
+    HIP_TRY(ctx, hipDeviceSynchronize());
     HIP_TRY(ctx, hipMemcpy(ctx->tab.cmvn_shift, shift, dim * sizeof(float), hipMemcpyHostToDevice));
     HIP_TRY(ctx, hipMemcpy(ctx->tab.cmvn_scale, scale, dim * sizeof(float), hipMemcpyHostToDevice));
     ctx->cmvn_loaded = true;
@@ -447,6 +462,35 @@ static int32_t up_layer_stream(asrfe_ctx* ctx, const HostTensor* wo, const HostT
     return upload(ctx, v, dev);
 }
 
+// ---- fp16 range proof ---------------------------------------------------------------------------
+// Every activation the kernels round to 16 bits is either bounded by construction (a normalised row has Euclidean
+// norm sqrt(K), so its entries stay below 23; probabilities stay below 1) or is a linear image of a normalised row:
+// |w . n + c| <= ||w||_2 sqrt(K) + |c| (Cauchy-Schwarz).  With fp16 operands the load call evaluates these bounds for
+// q, k, v, the attention output (a convex combination of v rows), the FSMN memory (v plus 11 taps of v) and the
+// feed-forward hidden layer, and refuses weights whose bound passes the largest fp16 number: such a model needs
+// ASRFE_DT_BF16.  (The kernels additionally convert with saturation, so even then no infinity would arise.)
+constexpr double kF16Max = 65504.0;
+static double linear_bound(const std::vector<float>& w, const std::vector<float>& c, int64_t rows, int64_t k, int64_t r0,
+                           int64_t r1, std::vector<double>* per_row = nullptr) {
+    double worst = 0.0;
+    for (int64_t r = r0; r < r1 && r < rows; ++r) {
+        double ss = 0.0;
+        for (int64_t i = 0; i < k; ++i) ss += static_cast<double>(w[r * k + i]) * w[r * k + i];
+        const double b = std::sqrt(ss) * std::sqrt(static_cast<double>(k)) + std::fabs(static_cast<double>(c[r]));
+        if (per_row) (*per_row)[r - r0] = b;
+        worst = std::fmax(worst, b);
+    }
+    return worst;
+}
+static int32_t range_refusal(asrfe_ctx* ctx, int layer, const char* what, double bound) {
+    char buf[256];
+    std::snprintf(buf, sizeof(buf),
+                  "asrfe_load_encoder_weights: layer %d %s can reach %.4g, beyond the fp16 range (65504): load this model "
+                  "with enc_compute_dtype = ASRFE_DT_BF16",
+                  layer, what, bound);
+    return set_err(ctx, ASRFE_ERR_RANGE, buf);
+}
+
 extern "C" int32_t asrfe_load_encoder_weights(asrfe_ctx* ctx, const asrfe_tensor_desc* descs, int32_t n) {
     if (!ctx || !descs || n <= 0) return set_err(ctx, ASRFE_ERR_BAD_ARG, "asrfe_load_encoder_weights: null argument");
     if (ctx->enc_loaded) return set_err(ctx, ASRFE_ERR_BAD_ARG, "asrfe_load_encoder_weights: weights already loaded");
@@ -479,6 +523,10 @@ extern "C" int32_t asrfe_load_encoder_weights(asrfe_ctx* ctx, const asrfe_tensor
         *w_shape = tw;
         return ASRFE_OK;
     };
+    const bool check_range = c.enc_compute_dtype == ASRFE_DT_F16;
+    // Row-major copies of a layer's matrices exist only for the launch plans that read them: the layer-0 projection
+    // always, the other projections when a layer's stream does not carry the next layer's Wqkv (or ASRFE_SEPARATE_QKV=1),
+    // Wo / W1 / W2 only under ASRFE_UNFUSED_FFN=1.  The default plan reads everything else from the piece stream.
     for (int li = 0; li < c.enc_num_blocks; ++li) {
         const std::string p = li == 0 ? std::string("encoders0.0") : "encoders." + std::to_string(li - 1);
         const int kpad = li == 0 ? ctx->kin_pad : static_cast<int>(d);
@@ -487,18 +535,35 @@ extern "C" int32_t asrfe_load_encoder_weights(asrfe_ctx* ctx, const asrfe_tensor
         const HostTensor *tg, *tb, *tw, *tc;
         std::vector<float> wfold, cfold;
         if ((rc = fold_qkv(li, wfold, cfold, &tw))) return rc;
+        std::vector<double> vbound(static_cast<size_t>(d), 0.0);
+        if (check_range) {
+            const int64_t din = tw->shape[1];
+            const double bq = linear_bound(wfold, cfold, 3 * d, din, 0, 2 * d);
+            if (bq > kF16Max) return range_refusal(ctx, li, "q / k", bq);
+            const double bv = linear_bound(wfold, cfold, 3 * d, din, 2 * d, 3 * d, &vbound);
+            if (bv > kF16Max) return range_refusal(ctx, li, "v (and the attention output)", bv);
+        }
         {
+            const bool prev_stream_has_it = li > 0 && ctx->layers[li - 1].stream_has_qkv && !ctx->separate_qkv && !ctx->unfused_ffn;
             const HostTensor view{wfold.data(), tw->shape};
-            if ((rc = up_bf16(ctx, &view, kpad, &L.w_qkv)) || (rc = upload(ctx, cfold, &L.b_qkv))) return rc;
+            if (!prev_stream_has_it && (rc = up_bf16(ctx, &view, kpad, &L.w_qkv))) return rc;
+            if ((rc = upload(ctx, cfold, &L.b_qkv))) return rc;
         }
         if ((rc = need(ctx, m, p + ".self_attn.fsmn_block.weight", {d, 1, ks}, &t))) return rc;
         {
             std::vector<float> w(static_cast<size_t>(ks) * d);
-            for (int64_t ch = 0; ch < d; ++ch)
-                for (int64_t j = 0; j < ks; ++j) w[j * d + ch] = t->data[ch * ks + j];
+            for (int64_t ch = 0; ch < d; ++ch) {
+                double gain = 1.0;
+                for (int64_t j = 0; j < ks; ++j) {
+                    w[j * d + ch] = t->data[ch * ks + j];
+                    gain += std::fabs(static_cast<double>(t->data[ch * ks + j]));
+                }
+                if (check_range && vbound[ch] * gain > kF16Max) return range_refusal(ctx, li, "FSMN memory", vbound[ch] * gain);
+            }
             if ((rc = upload(ctx, w, &L.w_fsmn))) return rc;
         }
-        if ((rc = need(ctx, m, p + ".self_attn.linear_out.weight", {d, d}, &t)) || (rc = up_bf16(ctx, t, static_cast<int>(d), &L.w_out))) return rc;
+        if ((rc = need(ctx, m, p + ".self_attn.linear_out.weight", {d, d}, &t))) return rc;
+        if (ctx->unfused_ffn && (rc = up_bf16(ctx, t, static_cast<int>(d), &L.w_out))) return rc;
         const HostTensor* t_wo = t;
         if ((rc = need(ctx, m, p + ".self_attn.linear_out.bias", {d}, &t)) || (rc = up_f32(ctx, t, &L.b_out))) return rc;
         if ((rc = need(ctx, m, p + ".norm2.weight", {d}, &tg)) || (rc = need(ctx, m, p + ".norm2.bias", {d}, &tb)) ||
@@ -507,8 +572,14 @@ extern "C" int32_t asrfe_load_encoder_weights(asrfe_ctx* ctx, const asrfe_tensor
             return rc;
         fold_layernorm(tw, tc, tg, tb, wfold, cfold);
         const HostTensor w1view{wfold.data(), tw->shape};
-        if ((rc = up_bf16(ctx, &w1view, static_cast<int>(d), &L.w_ffn1)) || (rc = upload(ctx, cfold, &L.b_ffn1))) return rc;
-        if ((rc = need(ctx, m, p + ".feed_forward.w_2.weight", {d, ff}, &t)) || (rc = up_bf16(ctx, t, static_cast<int>(ff), &L.w_ffn2))) return rc;
+        if (check_range) {
+            const double bh = linear_bound(wfold, cfold, ff, d, 0, ff);
+            if (bh > kF16Max) return range_refusal(ctx, li, "feed-forward hidden layer", bh);
+        }
+        if (ctx->unfused_ffn && (rc = up_bf16(ctx, &w1view, static_cast<int>(d), &L.w_ffn1))) return rc;
+        if ((rc = upload(ctx, cfold, &L.b_ffn1))) return rc;
+        if ((rc = need(ctx, m, p + ".feed_forward.w_2.weight", {d, ff}, &t))) return rc;
+        if (ctx->unfused_ffn && (rc = up_bf16(ctx, t, static_cast<int>(ff), &L.w_ffn2))) return rc;
         if (d != 512 || ff % 64 != 0 || ff > 7168)
             return set_err(ctx, ASRFE_ERR_SHAPE, "asrfe_load_encoder_weights: the fused post-attention kernel needs d = 512 and linear_units a multiple of 64 up to 7168");
         {

@@ -43,6 +43,7 @@ __global__ __launch_bounds__(kAttnThreads, 2) void attn_kernel(const AttnParams 
     // two K/V buffers: tile kt + 1 is fetched while tile kt is multiplied.  The FSMN phase stages its 144 rows in
     // bytes [32 KiB, 68 KiB), i.e. over buffer 1 plus 4 KiB, so that K and V tile 0 fly into buffer 0 at the same time.
     __shared__ __attribute__((aligned(16))) char smem[2 * kBufBytes + 4096 + kFsmnTapBytes];
+    saturate_fp16_conversions<F16>();
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);

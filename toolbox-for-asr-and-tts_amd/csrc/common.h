@@ -86,7 +86,6 @@ struct asrfe_ctx {
     float* after_b;
     float* pe_inv;  // [input_size/2] inverse timescales of the sinusoidal position code
     std::vector<void*> owned;  // every device allocation, freed in asrfe_destroy
-    std::string err;
     // optional per-kernel event timing (asrfe_profile_begin / _end)
     bool prof_on = false;
     std::vector<hipEvent_t> prof_events;  // start/stop pairs

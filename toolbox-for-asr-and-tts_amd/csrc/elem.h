@@ -16,6 +16,15 @@ typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
 typedef __attribute__((ext_vector_type(8))) uint16_t u16x8;
 typedef __attribute__((ext_vector_type(4))) uint16_t u16x4;
 
+// fp16 conversions saturate instead of overflowing: with the FP16_OVFL bit of the wave's MODE register set, a
+// conversion whose result would exceed the fp16 range gives +-65504 instead of +-inf (a true infinity stays one).
+// Called once at the top of every kernel that rounds activations to fp16; bf16 has the fp32 exponent range and
+// needs nothing.  hwreg(HW_REG_MODE = 1, offset 23, size 1) = 1 | 23 << 6 | (1 - 1) << 11.
+template <bool F16>
+__device__ __forceinline__ void saturate_fp16_conversions() {
+    if constexpr (F16) __builtin_amdgcn_s_setreg(1 | (23 << 6) | (0 << 11), 1);
+}
+
 template <bool F16>
 __device__ __forceinline__ uint16_t to_elem(float v) {
     if constexpr (F16) return __builtin_bit_cast(uint16_t, static_cast<_Float16>(v));

@@ -1,13 +1,15 @@
 // SAN-M encoder forward: carves the caller's workspace and enqueues the per-layer kernels.
 //
-// Per layer (d = 512):   h = LN1(x)                      ln kernel            bf16 [M][K]
-//                         qkv = h Wqkv^T + b              MFMA GEMM            bf16 [M][1536]
-//                         att = softmax(q k^T / sqrt(128)) v,  fsmn = FSMN(v)   attention kernel   16-bit [M][512] each
-//                         x = att Wo^T + b + fsmn (+ x)   MFMA GEMM            f32 [M][512]   (layer 0 has no residual)
-//                         h = LN2(x)                      ln kernel
-//                         f = relu(h W1^T + b)            MFMA GEMM            bf16 [M][2048]
-//                         x = f W2^T + b + x              MFMA GEMM            f32 [M][512]
-// The residual stream x stays fp32; GEMM inputs are bf16 with fp32 accumulation.
+// Default plan, two launches per layer (d = 512; 16-bit = the context's compute dtype, fp16 unless bf16 is chosen):
+//     layer 0 only:  h = n(feats sqrt(512) + PE)            ln kernel       16-bit [M][640]
+//                    qkv = h Wqkv^T + b                      MFMA GEMM       16-bit [M][1536]
+//     every layer:   att = softmax(q k^T / sqrt(128)) v,  fsmn = FSMN(v)     attention kernel   16-bit [M][512] each
+//                    x = att Wo^T + b + fsmn (+ x);  x += W2 relu(W1 n(x) + b1) + b2;  qkv of the NEXT layer
+//                                                             post-attention kernel   f32 [M][512], 16-bit [M][1536]
+//     at the end:    out = after_norm(x), rows past lens zero  ln kernel
+// ASRFE_SEPARATE_QKV=1 / ASRFE_UNFUSED_FFN=1 (read in asrfe_create) select the plans with more launches per layer
+// (a projection launch per layer; LayerNorm + four GEMM launches).  The residual stream x stays fp32; MFMA operands
+// are 16-bit with fp32 accumulation.
 #include <cmath>
 
 #include "common.h"
@@ -49,7 +51,8 @@ Buffers carve(const asrfe_ctx* ctx, void* ws, int B, int Tp) {
     b.qkv = c.take<uint16_t>(M * 1536);
     b.fsmn = c.take<uint16_t>(M * 512);
     b.att = c.take<uint16_t>(M * 512);
-    b.ffn = c.take<uint16_t>(M * ctx->cfg.enc_linear_units);
+    // the hidden layer exists in memory only under ASRFE_UNFUSED_FFN=1
+    b.ffn = ctx->unfused_ffn ? c.take<uint16_t>(M * ctx->cfg.enc_linear_units) : nullptr;
     b.pe = c.take<float>(static_cast<int64_t>(Tp) * ctx->cfg.enc_input_size);
     b.bytes = c.off;
     return b;

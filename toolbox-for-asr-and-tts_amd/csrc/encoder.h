@@ -62,5 +62,6 @@ struct FfnParams {
     long long* trace;      // timing build only: cycle-counter stamps of one wave (flags bit 8)
 };
 int32_t launch_post_attn(asrfe_ctx* ctx, const FfnParams& p, hipStream_t s);
+int32_t prepare_post_attn(asrfe_ctx* ctx);  // per-device kernel attributes; called by asrfe_create
 
 }  // namespace asrfe

@@ -43,6 +43,7 @@ struct LnParams {
 // MODE 2: final, f32 out, masked.  MODE 3: final, 16-bit out, masked.  F16 picks fp16 over bf16.
 template <int NV, int MODE, bool F16>
 __global__ __launch_bounds__(256) void ln_kernel(const LnParams p) {
+    saturate_fp16_conversions<F16>();
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= p.M) return;

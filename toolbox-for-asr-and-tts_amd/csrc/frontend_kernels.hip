@@ -269,7 +269,10 @@ __global__ __launch_bounds__(kWavesPerBlock * 64, 3) void fbank_kernel(const Fba
     for (int i = tid; i < kMelGroups * 16; i += kWavesPerBlock * 64) mel_sb[i] = p.tab.mel_sb[i];
 
     const int64_t len = p.pcm_lens[b];
-    const int T = len < kFrameLen ? 0 : 1 + static_cast<int>((len - kFrameLen) / kFrameShift);
+    // A clip with more frames than the output has rows is processed as if it had been cut after frame t_max - 1
+    // (fused mode: t_max = tp_max * lfr_n); the reported counts are those of the cut clip.
+    const int64_t t_all = len < kFrameLen ? 0 : 1 + (len - kFrameLen) / kFrameShift;
+    const int T = static_cast<int>(t_all < p.t_max ? t_all : p.t_max);
     const int Tp = (T + p.lfr_n - 1) / p.lfr_n;
     if (blockIdx.x == 0 && tid == 0) {
         if (p.n_frames) p.n_frames[b] = T;
@@ -304,7 +307,7 @@ __global__ __launch_bounds__(kWavesPerBlock * 64, 3) void fbank_kernel(const Fba
     // Samples [160 t0, 160 t0 + 880) of a group are fetched one group ahead, 8 per lane and pass, and wait in
     // registers while the previous group is computed.  Chunks that cross the end of the clip, and clips whose
     // address does not allow 16-byte loads, are read sample by sample when the group is staged.
-    const int t_lim = T < p.t_max ? T : p.t_max;
+    const int t_lim = T;
     auto group_t0 = [&](int g) { return blockIdx.x * kFramesPerBlock + (g * kWavesPerBlock + wave) * kFramesPerWave; };
     auto fast_chunk = [&](int t0, int c) {
         return vec_ok && c < kStageChunks && static_cast<int64_t>(kFrameShift) * t0 + 8 * c + 8 <= len;
@@ -515,8 +518,10 @@ __global__ __launch_bounds__(256) void lfr_cmvn_kernel(const float* __restrict__
                                                         int32_t* __restrict__ lens_out) {
     const int b = blockIdx.z;
     const int i = blockIdx.y;
-    const int T = n_frames[b];
-    const int Tp = (T + lfr_n - 1) / lfr_n;
+    // frames past the rows of logmel do not exist, LFR rows past the rows of feats are dropped
+    const int T = n_frames[b] < t_max ? (n_frames[b] < 0 ? 0 : n_frames[b]) : t_max;
+    const int Tp_all = (T + lfr_n - 1) / lfr_n;
+    const int Tp = Tp_all < tp_max ? Tp_all : tp_max;
     if (i == 0 && blockIdx.x == 0 && threadIdx.x == 0 && lens_out) lens_out[b] = Tp;
     const int dim = lfr_m * n_mels;
     const int col = blockIdx.x * blockDim.x + threadIdx.x;

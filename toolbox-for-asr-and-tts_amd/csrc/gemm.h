@@ -29,5 +29,6 @@ struct GemmParams {
 };
 
 int32_t launch_gemm(asrfe_ctx* ctx, const GemmParams& p, int epi, hipStream_t s);
+int32_t prepare_gemm(asrfe_ctx* ctx);  // per-device kernel attributes; called by asrfe_create
 
 }  // namespace asrfe

@@ -164,6 +164,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, const f32x16 
 template <int EPI, bool F16>
 __global__ __launch_bounds__(kGemmThreads) void gemm_bf16_kernel(const GemmParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    saturate_fp16_conversions<F16>();
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -334,6 +335,21 @@ __global__ __launch_bounds__(kGemmThreads) void gemm_bf16_kernel(const GemmParam
 #undef PHASE
 }
 
+// The dynamic-LDS limit of a kernel is a per-device attribute: asrfe_create calls this with the context's device
+// current, before any compute call can run.
+int32_t prepare_gemm(asrfe_ctx* ctx) {
+    const void* fns[6] = {reinterpret_cast<const void*>(gemm_bf16_kernel<EPI_BF16, false>),
+                          reinterpret_cast<const void*>(gemm_bf16_kernel<EPI_BF16_RELU, false>),
+                          reinterpret_cast<const void*>(gemm_bf16_kernel<EPI_F32_ADD, false>),
+                          reinterpret_cast<const void*>(gemm_bf16_kernel<EPI_BF16, true>),
+                          reinterpret_cast<const void*>(gemm_bf16_kernel<EPI_BF16_RELU, true>),
+                          reinterpret_cast<const void*>(gemm_bf16_kernel<EPI_F32_ADD, true>)};
+    for (const void* f : fns)
+        if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, kGemmLds) != hipSuccess)
+            return set_err(ctx, ASRFE_ERR_HIP, "gemm: cannot raise the dynamic LDS limit to 160 KiB");
+    return ASRFE_OK;
+}
+
 int32_t launch_gemm(asrfe_ctx* ctx, const GemmParams& pin, int epi, hipStream_t s) {
     GemmParams p = pin;
     if (p.M <= 0) return ASRFE_OK;
@@ -341,19 +357,6 @@ int32_t launch_gemm(asrfe_ctx* ctx, const GemmParams& pin, int epi, hipStream_t 
         return set_err(ctx, ASRFE_ERR_SHAPE, "gemm: N must be a multiple of 256, K of 128, leading dims of 8");
     p.n_tiles_m = (p.M + BM - 1) / BM;
     p.n_tiles_n = p.N / BN;
-    static bool attr_done = false;
-    if (!attr_done) {
-        const void* fns[6] = {reinterpret_cast<const void*>(gemm_bf16_kernel<EPI_BF16, false>),
-                              reinterpret_cast<const void*>(gemm_bf16_kernel<EPI_BF16_RELU, false>),
-                              reinterpret_cast<const void*>(gemm_bf16_kernel<EPI_F32_ADD, false>),
-                              reinterpret_cast<const void*>(gemm_bf16_kernel<EPI_BF16, true>),
-                              reinterpret_cast<const void*>(gemm_bf16_kernel<EPI_BF16_RELU, true>),
-                              reinterpret_cast<const void*>(gemm_bf16_kernel<EPI_F32_ADD, true>)};
-        for (const void* f : fns)
-            if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, kGemmLds) != hipSuccess)
-                return set_err(ctx, ASRFE_ERR_HIP, "gemm: cannot raise the dynamic LDS limit to 160 KiB");
-        attr_done = true;
-    }
     const int n_tiles = p.n_tiles_m * p.n_tiles_n;
     dim3 grid(n_tiles < ctx->num_cus ? n_tiles : ctx->num_cus), block(kGemmThreads);
     const bool f16 = ctx->cfg.enc_compute_dtype == ASRFE_DT_F16;

@@ -163,6 +163,7 @@ __device__ __forceinline__ u16x8 pack8(float a0, float a1, float a2, float a3, f
 template <bool F16, int OUT>
 __global__ __launch_bounds__(kFfnThreads) void post_attn_kernel(const FfnParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    saturate_fp16_conversions<F16>();
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -682,6 +683,21 @@ __global__ __launch_bounds__(kFfnThreads) void post_attn_kernel(const FfnParams 
     }
 }
 
+// The dynamic-LDS limit of a kernel is a per-device attribute: asrfe_create calls this with the context's device
+// current, before any compute call can run.
+int32_t prepare_post_attn(asrfe_ctx* ctx) {
+    const void* fns[6] = {reinterpret_cast<const void*>(post_attn_kernel<true, 0>),
+                          reinterpret_cast<const void*>(post_attn_kernel<true, 1>),
+                          reinterpret_cast<const void*>(post_attn_kernel<true, 2>),
+                          reinterpret_cast<const void*>(post_attn_kernel<false, 0>),
+                          reinterpret_cast<const void*>(post_attn_kernel<false, 1>),
+                          reinterpret_cast<const void*>(post_attn_kernel<false, 2>)};
+    for (const void* f : fns)
+        if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+            return set_err(ctx, ASRFE_ERR_HIP, "post_attn: cannot raise the dynamic LDS limit to 160 KiB");
+    return ASRFE_OK;
+}
+
 int32_t launch_post_attn(asrfe_ctx* ctx, const FfnParams& p, hipStream_t s) {
     if (p.M <= 0) return ASRFE_OK;
     if (p.ff < 64 || p.ff % 64 != 0 || p.ff > 7168)
@@ -697,17 +713,7 @@ int32_t launch_post_attn(asrfe_ctx* ctx, const FfnParams& p, hipStream_t s) {
     const int lds = kFfnRing + std::max(p.ff, kSlabFloats) * 4 + 2 * 512 * 4 + (out == 2 ? 1536 * 4 : 0);
     const dim3 grid((p.M + kFfnRows - 1) / kFfnRows), block(kFfnThreads);
     const bool f16 = ctx->cfg.enc_compute_dtype == ASRFE_DT_F16;
-#define POST_ATTN_LAUNCH(F, O)                                                                                  \
-    do {                                                                                                        \
-        static bool attr_done = false;                                                                          \
-        if (!attr_done) {                                                                                       \
-            if (hipFuncSetAttribute(reinterpret_cast<const void*>(post_attn_kernel<F, O>),                      \
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)      \
-                return set_err(ctx, ASRFE_ERR_HIP, "post_attn: cannot raise the dynamic LDS limit to 160 KiB"); \
-            attr_done = true;                                                                                   \
-        }                                                                                                       \
-        hipLaunchKernelGGL((post_attn_kernel<F, O>), grid, block, lds, s, p);                                   \
-    } while (0)
+#define POST_ATTN_LAUNCH(F, O) hipLaunchKernelGGL((post_attn_kernel<F, O>), grid, block, lds, s, p)
     if (f16) {
         if (out == 2) POST_ATTN_LAUNCH(true, 2);
         else if (out == 1) POST_ATTN_LAUNCH(true, 1);

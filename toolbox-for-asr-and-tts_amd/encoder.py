@@ -4,7 +4,8 @@ The reference reaches ``SANMEncoder.forward(xs_pad, ilens)`` inside the ModelSco
 builds at /root/reference/voice-service/app/services/voice_interface.py:832-841 and calls at
 :2049-2053.  Constructor arguments, ``state_dict`` key names (``encoders0.0.*``, ``encoders.N.*``,
 ``after_norm.*``) and the ``(xs_pad, olens, None)`` return follow that class.  All arithmetic runs in
-the HIP library (bf16 MFMA GEMMs with fp32 accumulation, fp32 residual stream); there is no CPU path.
+the HIP library (fp16 MFMA operands by default, bf16 selectable, fp32 accumulation, fp32 residual stream);
+there is no CPU path.
 """
 from __future__ import annotations
 

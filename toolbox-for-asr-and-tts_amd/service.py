@@ -25,6 +25,9 @@ takes it as a callable ``decoder(encoder_out [1, T', 512], lengths [1]) -> str``
 request and ignored (they belong to the reference's control plane)."""
 from __future__ import annotations
 
+import asyncio
+import contextlib
+from concurrent.futures import ThreadPoolExecutor
 from typing import Callable, Optional
 
 import torch
@@ -93,6 +96,18 @@ def create_app(engine, decoder: Optional[Callable] = None, clock: Optional[Calla
     ``engine``: an ``AsrEngine(batch=1, max_samples=...)`` (anything with ``run``, ``device`` and
     ``max_samples`` serves, which is how the CPU tests drive the route)."""
     app = FastAPI(title="voice")
+    # The reference calls its models on the event-loop thread (voice.py:613, voice_interface.py:2049), which stalls
+    # every other connection for the length of a recognition.  Here the engine runs on ONE worker thread: requests
+    # queue up behind each other (an engine is a single batch slot and is not re-entrant) while the loop stays free.
+    worker = ThreadPoolExecutor(max_workers=1, thread_name_prefix="asr-engine")
+
+    async def on_engine(fn, *args):
+        def call():
+            dev = getattr(engine, "device", None)
+            guard = torch.cuda.device(dev) if isinstance(dev, torch.device) and dev.type == "cuda" else contextlib.nullcontext()
+            with guard:
+                return fn(*args)
+        return await asyncio.get_running_loop().run_in_executor(worker, call)
 
     @app.get("/health")
     async def health_check():
@@ -103,7 +118,7 @@ def create_app(engine, decoder: Optional[Callable] = None, clock: Optional[Calla
         try:
             if not request.audio_data or len(request.audio_data) < 100:
                 raise HTTPException(status_code=400, detail="audio data missing or too short")
-            result = recognize(engine, request, decoder)
+            result = await on_engine(recognize, engine, request, decoder)
             return JSONResponse(content=result.model_dump(), headers={"Content-Type": "application/json; charset=utf-8"})
         except HTTPException:
             raise
@@ -152,14 +167,19 @@ def create_app(engine, decoder: Optional[Callable] = None, clock: Optional[Calla
                     if state["should_finalize"]:
                         await websocket.send_json({"type": "processing", "status": "finalizing",
                                                    "message": "processing audio"})
-                        final_text = finalize_session(engine, session, decoder)
+                        try:
+                            final_text = await on_engine(finalize_session, engine, session, decoder)
+                        finally:
+                            # whatever happened to the utterance, the session starts over (the reference resets its
+                            # recognition state after every finalize, voice.py:878): a failed utterance, e.g. one
+                            # longer than the engine takes, must not be retried on every following silent chunk
+                            session.reset(now())
                         if final_text:
                             await websocket.send_json({"type": "result", "status": "completed", "text": final_text,
                                                        "success": True})
                         else:
                             await websocket.send_json({"type": "result", "status": "completed", "text": "",
                                                        "success": False, "message": "nothing recognised, please repeat"})
-                        session.reset(now())
                 except Exception as e:
                     await websocket.send_json({"type": "error", "message": f"chunk processing failed: {e}",
                                                "code": "PROCESSING_ERROR"})

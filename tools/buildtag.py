@@ -1,0 +1,23 @@
+"""Tag of the kernel sources a measurement was taken with: sha256 over the files of csrc/ and include/asrfe.h.
+Counter profiles under profiles/ record it; bench.py only quotes a profile whose tag equals that of the tree it
+runs from, so numbers of an older build cannot be mistaken for this one's."""
+import glob
+import hashlib
+import os
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def csrc_tag() -> str:
+    h = hashlib.sha256()
+    files = sorted(glob.glob(os.path.join(ROOT, "toolbox-for-asr-and-tts_amd", "csrc", "*")))
+    files.append(os.path.join(ROOT, "include", "asrfe.h"))
+    for f in files:
+        if os.path.isfile(f) and f.endswith((".hip", ".cpp", ".h", "Makefile")):
+            h.update(os.path.basename(f).encode())
+            h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
+if __name__ == "__main__":
+    print(csrc_tag())
