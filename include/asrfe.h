@@ -158,6 +158,17 @@ int32_t asrfe_encoder_forward(asrfe_ctx* ctx, const float* feats, const int32_t*
                               int32_t tp, void* out, int32_t out_dtype, void* workspace,
                               int64_t workspace_bytes, void* stream);
 
+/* The same forward for callers that cannot allocate device memory (code under HIP graph capture, tight serving
+ * loops, harnesses that forbid hipMalloc): no workspace argument.  No counterpart in the reference.  The scratch is a
+ * device array inside the library, ASRFE_STATIC_SCRATCH_BYTES per GPU for the life of the process; a [batch, tp]
+ * call needs asrfe_encoder_workspace_bytes(ctx, batch, tp) of it (about 8.3 KiB per row: up to ~3970 rows, e.g.
+ * 7 clips of 30 s or 79 of 3 s) and larger calls are refused with ASRFE_ERR_WORKSPACE.  The call allocates nothing
+ * and only enqueues kernels on `stream`.  All calls on one GPU share the array: calls that overlap on one GPU
+ * (different streams without ordering, or threads) race; calls ordered on one stream do not. */
+#define ASRFE_STATIC_SCRATCH_BYTES (32ll << 20)
+int32_t asrfe_encoder_forward_static(asrfe_ctx* ctx, const float* feats, const int32_t* lens, int32_t batch,
+                                     int32_t tp, void* out, int32_t out_dtype, void* stream);
+
 /* Host-only table builders (double precision, no device needed): the Kaldi mel banks over bins
  * 0 .. n_fft/2 - 1 as [n_mels][n_fft/2], and the analysis window [frame_length].  These are the
  * tables asrfe_create uploads; they stand in for torchaudio's get_mel_banks / _feature_window_function

@@ -93,6 +93,8 @@ SIGNATURES = {
     "asrfe_encoder_workspace_bytes": (C.c_int64, [C.c_void_p, C.c_int32, C.c_int32]),
     "asrfe_encoder_forward": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p,
                                           C.c_int32, C.c_void_p, C.c_int64, C.c_void_p]),
+    "asrfe_encoder_forward_static": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p,
+                                                 C.c_int32, C.c_void_p]),
     "asrfe_host_mel_banks": (C.c_int32, [C.POINTER(Config), C.POINTER(C.c_double)]),
     "asrfe_host_window": (C.c_int32, [C.POINTER(Config), C.POINTER(C.c_double)]),
     "asrfe_profile_begin": (C.c_int32, [C.c_void_p, C.c_int32]),

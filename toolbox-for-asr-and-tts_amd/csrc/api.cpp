@@ -282,7 +282,8 @@ extern "C" int32_t asrfe_create(const asrfe_config* cfg, asrfe_ctx** out) {
     if ((rc = upload(ctx, inv, &ctx->pe_inv))) return fail(rc);
 
     // per-device kernel attributes (dynamic LDS above 64 KiB), set here so that no compute call ever has to
-    if ((rc = prepare_gemm(ctx)) || (rc = prepare_post_attn(ctx))) return fail(rc);
+    if ((rc = prepare_gemm(ctx)) || (rc = prepare_post_attn(ctx)) || (rc = prepare_static_scratch(ctx)))
+        return fail(rc);
 
     *out = ctx;
     return ASRFE_OK;

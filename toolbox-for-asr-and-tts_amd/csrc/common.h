@@ -117,6 +117,7 @@ int32_t set_err(asrfe_ctx* ctx, int32_t code, const std::string& msg);
 int32_t launch_fbank(asrfe_ctx* ctx, const FbankParams& p, int pcm_dtype, bool fused, int out_dtype, hipStream_t s);
 int32_t launch_lfr_cmvn(asrfe_ctx* ctx, const float* logmel, const int32_t* n_frames, int batch, int t_max,
                         int tp_max, void* feats, int out_dtype, int32_t* lens_out, hipStream_t s);
+int32_t prepare_static_scratch(asrfe_ctx* ctx);  // static_scratch.hip: device address of the library's scratch array
 int64_t encoder_workspace_bytes(const asrfe_ctx* ctx, int batch, int tp);
 int32_t encoder_forward(asrfe_ctx* ctx, const float* feats, const int32_t* lens, int batch, int tp, void* out,
                         int out_dtype, void* ws, int64_t ws_bytes, hipStream_t s);
