@@ -24,7 +24,10 @@ def main():
     ap.add_argument("--repeat", type=int, default=2)
     ap.add_argument("--flags", type=int, nargs="*", default=[0])
     ap.add_argument("--qkv", action="store_true", help="time the variant that also projects the next layer's q, k, v")
+    ap.add_argument("--lib", default=None, help="path of another build of libasrfe.so (A/B runs of experiment builds)")
     args = ap.parse_args()
+    if args.lib:
+        pkg._lib.LIB_PATH = os.path.abspath(args.lib)
     enc = pkg.SANMEncoder(num_blocks=2)
     sd = encoder_state_dict(num_blocks=2, seed=3)
     gen = torch.Generator().manual_seed(5)
