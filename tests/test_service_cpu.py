@@ -165,3 +165,56 @@ def test_websocket_recovers_after_an_utterance_the_engine_refuses():
         for lv in [6000, 7000] + [30] * 8:
             got += send(ws, lv)
         assert [m["type"] for m in got] == ["processing", "result"] and got[1]["success"] is True
+
+
+@pytest.mark.timeout(60)
+def test_websocket_control_messages_and_sentinels():
+    """end_conversation / cancel_enrollment are confirmed with the reference's status messages and reset the session;
+    start_asr outside the enrolment modes is ignored; the session's sentinel strings become the reference's result
+    messages (voice.py:227-303, 635-664)."""
+    t = [100.0]
+    eng = FakeEngine()
+    answers = iter(["__SV_VERIFICATION_FAILED__", "__SV_NOT_ACTIVATED__", "__ASR_RESULT_EMPTY__", "", "好的"])
+    client = TestClient(svc.create_app(eng, decoder=lambda out, ol: next(answers), clock=lambda: t[0]))
+    rng = np.random.default_rng(5)
+
+    def utterance(ws):
+        out = []
+        for lv in [6000, 7000] + [30] * 8:
+            t[0] += 0.4
+            ws.send_text(json.dumps({"wav_base64": wav_b64(rng.normal(0, lv, 6400).astype(np.int16))}))
+            ws.send_text("sync")
+            while True:
+                m = ws.receive_json()
+                if m.get("code") == "INVALID_JSON":
+                    break
+                out.append(m)
+            if out and out[-1]["type"] == "result":
+                return out[-1]
+        raise AssertionError(out)
+
+    with client.websocket_connect("/api/v1/voice/asr/ws") as ws:
+        assert ws.receive_json()["type"] == "welcome"
+        ws.send_text(json.dumps({"type": "end_conversation"}))
+        assert ws.receive_json() == {"type": "status", "status": "conversation_ended", "message": "会话已结束，状态已重置"}
+        ws.send_text(json.dumps({"type": "cancel_enrollment"}))
+        m = ws.receive_json()
+        assert m["type"] == "status" and m["status"] == "enrollment_cancelled"
+        ws.send_text(json.dumps({"type": "start_asr"}))      # no answer: the next message is the one for "sync"
+        ws.send_text("sync")
+        assert ws.receive_json()["code"] == "INVALID_JSON"
+        want = [("", False, "抱歉，请再说一遍！"), ("", False, "非认证注册声音，拒绝访问。"), ("", False, "抱歉，请再说一遍！"),
+                ("", False, "抱歉，请再说一遍！"), ("好的", True, None)]
+        for text, ok, msg in want:
+            r = utterance(ws)
+            assert (r["text"], r["success"], r.get("message")) == (text, ok, msg)
+        # a control message in the middle of an utterance drops what was heard so far
+        t[0] += 0.4
+        ws.send_text(json.dumps({"wav_base64": wav_b64(rng.normal(0, 7000, 6400).astype(np.int16))}))
+        ws.send_text(json.dumps({"type": "end_conversation"}))
+        assert ws.receive_json()["status"] == "conversation_ended"
+        for _ in range(8):                                    # silence only: nothing to finalize
+            t[0] += 0.4
+            ws.send_text(json.dumps({"wav_base64": wav_b64(rng.normal(0, 30, 6400).astype(np.int16))}))
+        ws.send_text("sync")
+        assert ws.receive_json()["code"] == "INVALID_JSON"

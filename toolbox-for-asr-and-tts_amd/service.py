@@ -14,7 +14,12 @@ Mirrors, for the one route that reaches the hot path, what a client of the refer
   device runs through the engine and the decoder, and ``{"type": "result", "status": "completed", "text", "success"}``
   follows; malformed input is answered with ``{"type": "error", "message", "code"}`` using the reference's codes
   (EMPTY_MESSAGE, INVALID_JSON, MISSING_AUDIO_DATA, AUDIO_DECODE_ERROR, PROCESSING_ERROR) and the connection stays
-  open.  Wake-word activation, speaker enrolment / verification and LLM correction messages are not served.
+  open.  The control messages are answered as there (voice.py:227-303): ``end_conversation`` and ``cancel_enrollment``
+  reset the session and are confirmed with a ``status`` message, ``start_asr`` is only honoured in the enrolment
+  modes, which this service never enters, so it is ignored without an answer as the reference does outside them.
+  A decoder may return the reference session's sentinel strings (voice_interface.py:1922, 2187, 2217) and they are
+  turned into the same client messages (voice.py:635-664).  Wake-word activation, speaker enrolment / verification
+  and LLM correction themselves are not served.
 
 What runs behind the route is this package: base64 WAV -> ``decode_wav_base64`` -> float32 samples in [-1, 1) ->
 ``AsrEngine`` (float PCM is scaled by 32768 in the fbank kernel, as FunASR's loader does with the WAV file the
@@ -52,6 +57,24 @@ class ASRResponse(BaseModel):
     success: bool
     message: Optional[str] = None
     sample_id: Optional[str] = None
+
+
+# What the reference's session returns instead of text when there is nothing to show, and what the route tells the client
+# (voice-service/app/api/voice.py:635-664; the message texts are part of the wire protocol).
+SENTINEL_MESSAGES = {
+    "__SV_VERIFICATION_FAILED__": "抱歉，请再说一遍！",
+    "__SV_NOT_ACTIVATED__": "非认证注册声音，拒绝访问。",
+    "__ASR_RESULT_EMPTY__": "抱歉，请再说一遍！",
+}
+EMPTY_RESULT_MESSAGE = "抱歉，请再说一遍！"
+
+
+def result_message(final_text: str) -> dict:
+    """The ``result`` message for what finalize returned: text, a sentinel, or nothing."""
+    if final_text and final_text not in SENTINEL_MESSAGES:
+        return {"type": "result", "status": "completed", "text": final_text, "success": True}
+    return {"type": "result", "status": "completed", "text": "", "success": False,
+            "message": SENTINEL_MESSAGES.get(final_text, EMPTY_RESULT_MESSAGE)}
 
 
 def recognize(engine, request: ASRRequest, decoder: Optional[Callable] = None) -> ASRResponse:
@@ -151,6 +174,19 @@ def create_app(engine, decoder: Optional[Callable] = None, clock: Optional[Calla
                 except json.JSONDecodeError:
                     await websocket.send_json({"type": "error", "message": "messages must be JSON", "code": "INVALID_JSON"})
                     continue
+                kind = data.get("type") if isinstance(data, dict) else None
+                if kind == "end_conversation":      # the user left: everything starts over (voice.py:227-237)
+                    session.reset(now())
+                    await websocket.send_json({"type": "status", "status": "conversation_ended",
+                                               "message": "会话已结束，状态已重置"})
+                    continue
+                if kind == "cancel_enrollment":     # voice.py:240-264 (there the session also falls back to wake-word mode)
+                    session.reset(now())
+                    await websocket.send_json({"type": "status", "status": "enrollment_cancelled",
+                                               "message": "声纹录制已取消，已回退到等待唤醒状态"})
+                    continue
+                if kind == "start_asr":             # only meaningful while enrolling (voice.py:267-302): ignored here
+                    continue
                 wav_b64 = (data.get("wav_base64") or data.get("audio_data")) if isinstance(data, dict) else None
                 if not wav_b64 or not isinstance(wav_b64, str):
                     await websocket.send_json({"type": "error", "message": "field 'wav_base64' or 'audio_data' missing",
@@ -174,12 +210,7 @@ def create_app(engine, decoder: Optional[Callable] = None, clock: Optional[Calla
                             # recognition state after every finalize, voice.py:878): a failed utterance, e.g. one
                             # longer than the engine takes, must not be retried on every following silent chunk
                             session.reset(now())
-                        if final_text:
-                            await websocket.send_json({"type": "result", "status": "completed", "text": final_text,
-                                                       "success": True})
-                        else:
-                            await websocket.send_json({"type": "result", "status": "completed", "text": "",
-                                                       "success": False, "message": "nothing recognised, please repeat"})
+                        await websocket.send_json(result_message(final_text))
                 except Exception as e:
                     await websocket.send_json({"type": "error", "message": f"chunk processing failed: {e}",
                                                "code": "PROCESSING_ERROR"})
