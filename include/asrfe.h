@@ -158,6 +158,51 @@ int32_t asrfe_encoder_forward(asrfe_ctx* ctx, const float* feats, const int32_t*
                               int32_t tp, void* out, int32_t out_dtype, void* workspace,
                               int64_t workspace_bytes, void* stream);
 
+/* ---- the step behind the encoder: CIF predictor + Paraformer SAN-M decoder + greedy token choice ----------------
+ * Stands in for what the reference's pipeline call (voice_interface.py:2049-2053) does with the encoder output before
+ * it returns text (consumed at voice_interface.py:2056-2067, 2108-2181): FunASR's CifPredictorV2.forward,
+ * ParaformerSANMDecoder.forward and the arg-max of Paraformer.inference.  Turning token ids into characters needs the
+ * model directory's token list and is host code (the Python mirror takes it as an argument). */
+typedef struct asrfe_decoder_config {
+    int32_t num_blocks;      /* 16 decoder blocks with FSMN + cross-attention (att_layer_num == num_blocks), then one
+                                feed-forward-only block, after_norm and the output layer */
+    int32_t linear_units;    /* 2048 (a multiple of 512 up to 4096) */
+    int32_t kernel_size;     /* 11 - only 11 is built */
+    int32_t vocab_size;      /* 8404 */
+    float ln_eps;            /* 1e-12 */
+    float threshold;         /* CIF firing threshold, 1.0 - only 1.0 is built (the reference subtracts a literal 1) */
+    float tail_threshold;    /* 0.45 */
+    float smooth_factor;     /* 1.0 */
+    float noise_threshold;   /* 0.0 */
+} asrfe_decoder_config;
+int32_t asrfe_default_decoder_config(asrfe_decoder_config* cfg);
+
+/* model.pt tensors "predictor.*" and "decoder.*" (host float32, FunASR names); needs an encoder width of 512.  With
+ * fp16 operands the same range proof as asrfe_load_encoder_weights runs over the linear layers behind a LayerNorm. */
+int32_t asrfe_load_decoder_weights(asrfe_ctx* ctx, const asrfe_decoder_config* cfg, const asrfe_tensor_desc* descs, int32_t n);
+
+/* Device scratch for asrfe_cif_predictor + asrfe_decoder_forward on [batch, tp] encoder frames and up to n_max tokens per
+ * utterance, and the row stride of the logits (vocab_size rounded up to a multiple of 256). */
+int64_t asrfe_decoder_workspace_bytes(const asrfe_ctx* ctx, int32_t batch, int32_t tp, int32_t n_max);
+int32_t asrfe_decoder_logits_stride(const asrfe_ctx* ctx);
+
+/* CifPredictorV2.forward: enc_out [B, tp, 512] float32 (rows >= lens[b] are not read), lens [B] ->
+ * embeds [B, n_max, 512] float32 (token n's integrate-and-fire sum of frames; rows past the fired tokens zero),
+ * token_num [B] int32 = floor of the summed alphas incl. the tail weight, capped at n_max (tokens beyond n_max are
+ * dropped: size n_max for the longest utterance, tp + 1 is always enough), and optionally alphas_out [B, tp + 1]. */
+int32_t asrfe_cif_predictor(asrfe_ctx* ctx, const float* enc_out, const int32_t* lens, int32_t batch, int32_t tp,
+                            int32_t n_max, float* embeds, int32_t* token_num, float* alphas_out, void* workspace,
+                            int64_t workspace_bytes, void* stream);
+
+/* ParaformerSANMDecoder.forward + arg-max: memory = enc_out [B, tp, 512] float32 with lens [B], embeds [B, n_max, 512]
+ * and token_num [B] as asrfe_cif_predictor leaves them -> token_ids [B, n_max] int32 (arg-max over the vocabulary for
+ * rows < token_num[b], -1 behind them; sos / eos / blank are left in: dropping them is the host's one-line filter) and
+ * optionally logits [B * n_max, asrfe_decoder_logits_stride] float32 (columns >= vocab_size are padding).  Must run on
+ * the same workspace right behind asrfe_cif_predictor (it reuses the 16-bit copy of enc_out that call leaves there). */
+int32_t asrfe_decoder_forward(asrfe_ctx* ctx, const float* enc_out, const int32_t* lens, int32_t batch, int32_t tp,
+                              const float* embeds, const int32_t* token_num, int32_t n_max, int32_t* token_ids,
+                              float* logits, void* workspace, int64_t workspace_bytes, void* stream);
+
 /* The same forward for callers that cannot allocate device memory (code under HIP graph capture, tight serving
  * loops, harnesses that forbid hipMalloc): no workspace argument.  No counterpart in the reference.  The scratch is a
  * device array inside the library, ASRFE_STATIC_SCRATCH_BYTES per GPU for the life of the process; a [batch, tp]

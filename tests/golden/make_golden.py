@@ -23,7 +23,11 @@ Files written:
                                  each) through the whole oracle chain, fbank -> LFR -> CMVN (identity) -> 50 blocks in
                                  fp64 with the benchmark's weights: selected feature rows and encoder rows, column sums
 
-``python tests/golden/make_golden.py full`` writes only the last two (several minutes of CPU time).
+  decoder_tiny.npz             : CIF predictor + 2-block decoder (vocabulary 300), B=2, T'=48 ragged: memory, alphas,
+                                 token counts, embeddings, logits, arg-max ids (fp64 oracle)
+
+``python tests/golden/make_golden.py full`` writes only the two full-size encoder fixtures (several minutes of CPU
+time), ``... decoder`` only the decoder fixture.
 """
 from __future__ import annotations
 
@@ -145,9 +149,36 @@ def full_size_goldens():
     print("bench clips 50l:", tuple(out.shape), "abs mean", float(np.abs(o).mean()))
 
 
+def decoder_goldens():
+    """CIF predictor + decoder, tiny: 2 blocks, vocabulary 300, B = 2, T' = 48 ragged (fp64 oracle)."""
+    from oracle import paraformer_decoder_oracle as po
+
+    cfg = po.DecoderConfig(num_blocks=2, vocab_size=300)
+    sd = {k: v.double() for k, v in po.make_state_dict(cfg, seed=7).items()}
+    g = torch.Generator().manual_seed(8)
+    mem = torch.randn(2, 48, 512, generator=g, dtype=torch.float32).double()
+    lens = torch.tensor([48, 31], dtype=torch.int32)
+    ids, logits, tn, alphas = po.recognize(mem, lens, sd, cfg)
+    emb, _, _, _ = po.predictor_forward(mem, lens, sd, cfg)
+    n = int(tn.max())
+    idm = np.full((2, n), -1, np.int32)
+    for k in range(2):
+        idm[k, : int(tn[k])] = logits[k, : int(tn[k])].argmax(-1).numpy()
+    np.savez_compressed(
+        os.path.join(OUT, "decoder_tiny.npz"),
+        memory=mem.numpy().astype(np.float32), lens=lens.numpy(), token_num=tn.numpy(), alphas=alphas.numpy(),
+        embeds=emb.numpy().astype(np.float32), logits=logits.numpy().astype(np.float32), ids=idm,
+        seed=np.int32(7), num_blocks=np.int32(2), vocab_size=np.int32(300),
+    )
+    print("decoder tiny: token_num", tn.tolist(), "logits", tuple(logits.shape))
+
+
 def main():
     if len(sys.argv) > 1 and sys.argv[1] == "full":
         full_size_goldens()
+        return
+    if len(sys.argv) > 1 and sys.argv[1] == "decoder":
+        decoder_goldens()
         return
     worst = 0.0
     for kind, seed, n in FBANK_CASES:

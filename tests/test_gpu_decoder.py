@@ -1,0 +1,194 @@
+"""GPU parity of the step behind the encoder (CIF predictor + Paraformer SAN-M decoder + arg-max), called through the
+C ABI, against the CPU oracle (oracle/paraformer_decoder_oracle.py, fp64) and the committed fixture.  Bars: alphas to
+1e-5, token counts exact, token embeddings to 1e-4, logits to 3e-2 (16-bit MFMA operands through up to 17 blocks and
+the vocabulary projection), token ids exact wherever the oracle's best logit leads the runner-up by more than twice
+that."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import paraformer_decoder_oracle as po
+
+pytestmark = pytest.mark.gpu
+
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
+ALPHA_TOL, EMB_TOL, LOGIT_TOL = 1e-5, 1e-4, 3e-2
+
+
+@pytest.fixture(scope="module")
+def pkg():
+    import toolbox_for_asr_and_tts_amd as p
+
+    p.load()
+    return p
+
+
+def make_head(pkg, cfg, sd):
+    from toolbox_for_asr_and_tts_amd.decoder import ParaformerHead
+    head = ParaformerHead(pkg.Context(), num_blocks=cfg.num_blocks, linear_units=cfg.linear_units, vocab_size=cfg.vocab_size)
+    head.load_state_dict(sd)
+    return head
+
+
+def check_against_oracle(head, cfg, sd, mem, lens, n_max=None):
+    sd64 = {k: v.double() for k, v in sd.items()}
+    want_ids, want_logits, want_tn, want_alphas = po.recognize(mem.double(), lens, sd64, cfg)
+    want_emb, _, _, _ = po.predictor_forward(mem.double(), lens, sd64, cfg)
+    r = head.forward(mem.cuda(), lens, n_max=n_max, return_logits=True, return_alphas=True)
+    torch.cuda.synchronize()
+    assert float((r["alphas"].cpu().double() - want_alphas).abs().max()) <= ALPHA_TOL
+    assert r["token_num"].cpu().tolist() == want_tn.tolist()
+    worst = 0.0
+    for k in range(mem.shape[0]):
+        n = int(want_tn[k])
+        if n == 0:
+            assert torch.all(r["token_ids"][k] == -1)
+            continue
+        assert float((r["embeds"][k, :n].cpu().double() - want_emb[k, :n]).abs().max()) <= EMB_TOL
+        assert float(r["embeds"][k, n:].abs().max()) == 0.0 if n < r["embeds"].shape[1] else True
+        got = r["logits"][k, :n].cpu().double()
+        err = float((got - want_logits[k, :n]).abs().max())
+        worst = max(worst, err)
+        assert err <= LOGIT_TOL, (k, err)
+        top2 = want_logits[k, :n].topk(2, dim=-1).values
+        sure = (top2[:, 0] - top2[:, 1]) > 2 * LOGIT_TOL
+        ids = r["token_ids"][k, :n].cpu()
+        assert torch.equal(ids[sure], want_logits[k, :n].argmax(-1)[sure].to(torch.int32))
+        assert torch.equal(ids, got.argmax(-1).to(torch.int32))          # the arg-max kernel agrees with its own logits
+        assert torch.all(r["token_ids"][k, n:] == -1)
+    return worst
+
+
+def test_decoder_tiny_fixture(pkg):
+    g = np.load(os.path.join(GOLDEN, "decoder_tiny.npz"))
+    cfg = po.DecoderConfig(num_blocks=int(g["num_blocks"]), vocab_size=int(g["vocab_size"]))
+    sd = po.make_state_dict(cfg, seed=int(g["seed"]))
+    head = make_head(pkg, cfg, sd)
+    mem = torch.from_numpy(g["memory"])
+    r = head.forward(mem.cuda(), torch.from_numpy(g["lens"]), return_logits=True, return_alphas=True)
+    torch.cuda.synchronize()
+    assert np.max(np.abs(r["alphas"].cpu().numpy() - g["alphas"])) <= ALPHA_TOL
+    assert r["token_num"].cpu().tolist() == g["token_num"].tolist()
+    for k in range(2):
+        n = int(g["token_num"][k])
+        assert np.max(np.abs(r["embeds"][k, :n].cpu().numpy() - g["embeds"][k, :n])) <= EMB_TOL
+        assert np.max(np.abs(r["logits"][k, :n].cpu().numpy() - g["logits"][k, :n])) <= LOGIT_TOL
+    assert r["logits"].shape[2] == 300 and head.logits_stride == 512
+
+
+def test_predictor_and_decoder_ragged_lengths(pkg):
+    """Lengths around the edges: an empty utterance (no tokens), a single frame, lengths that end a 64-key tile."""
+    cfg = po.DecoderConfig(num_blocks=2, vocab_size=515)
+    sd = po.make_state_dict(cfg, seed=11)
+    head = make_head(pkg, cfg, sd)
+    g = torch.Generator().manual_seed(12)
+    mem = torch.randn(5, 130, 512, generator=g)
+    lens = torch.tensor([130, 64, 1, 0, 65], dtype=torch.int32)
+    check_against_oracle(head, cfg, sd, mem, lens)
+
+
+def test_full_size_decoder(pkg):
+    """The paraformer-large head: 16 blocks + closing block, linear_units 2048, vocabulary 8404; B = 2, T' = 100."""
+    cfg = po.DecoderConfig()
+    sd = po.make_state_dict(cfg, seed=13)
+    head = make_head(pkg, cfg, sd)
+    g = torch.Generator().manual_seed(14)
+    mem = torch.randn(2, 100, 512, generator=g)
+    lens = torch.tensor([100, 73], dtype=torch.int32)
+    worst = check_against_oracle(head, cfg, sd, mem, lens)
+    print(f"full-size decoder: worst logit error {worst:.3e}")
+    # n_max below the token count truncates: the first n_max tokens are the same tokens
+    full = head.forward(mem.cuda(), lens)
+    n_cut = 12
+    cut = head.forward(mem.cuda(), lens, n_max=n_cut, return_logits=True)
+    torch.cuda.synchronize()
+    assert cut["token_num"].cpu().tolist() == [min(int(t), n_cut) for t in full["token_num"].cpu().tolist()]
+    assert torch.equal(cut["embeds"], full["embeds"][:, :n_cut])
+
+
+def test_engine_to_token_ids(pkg):
+    """PCM -> frontend -> encoder -> predictor -> decoder on the device; the head's result equals the oracle head run
+    on the device encoder's own output (the oracle encoder's output differs by the encoder tolerance, which moves
+    integrate-and-fire decisions: the two halves are held to their own bars)."""
+    from oracle import fbank_oracle as fo
+    from oracle import sanm_oracle as so
+    from toolbox_for_asr_and_tts_amd.decoder import ParaformerHead
+    n = 48000
+    clips = np.stack([fo.synth_pcm("bursts", n, 70), fo.synth_pcm("gauss", n, 71)])
+    lens = [48000, 30000]
+    cfg_e = pkg.default_config()
+    cfg_e.enc_num_blocks = 2
+    eng = pkg.AsrEngine(batch=2, max_samples=n, cfg=cfg_e, state_dict=so.make_state_dict(so.SanmConfig(num_blocks=2), seed=2))
+    cfg = po.DecoderConfig(num_blocks=2, vocab_size=300)
+    sd = po.make_state_dict(cfg, seed=15)
+    head = ParaformerHead(eng.ctx, num_blocks=2, vocab_size=300)     # shares the engine's context
+    head.load_state_dict(sd)
+    out, olens = eng.run(torch.from_numpy(clips).cuda(), torch.tensor(lens, dtype=torch.int32, device="cuda"))
+    ids = head.recognize(out, olens)
+    torch.cuda.synchronize()
+    want_ids, _, want_tn, _ = po.recognize(out.cpu().double(), olens.cpu(), {k: v.double() for k, v in sd.items()}, cfg)
+    assert [len(i) for i in ids] == [len(i) for i in want_ids]
+    agree = sum(a == b for x, y in zip(ids, want_ids) for a, b in zip(x, y))
+    total = sum(len(x) for x in want_ids)
+    assert total > 0 and agree >= 0.9 * total, (agree, total)   # random-weight logits are nearly flat: near-ties may differ
+    # with a token list the ids become text
+    head.token_list = [f"t{i}" if i % 3 else chr(0x4E00 + i) for i in range(300)]
+    texts = head.recognize(out, olens)
+    assert len(texts) == 2 and all(isinstance(t, str) and t for t in texts)
+
+
+def test_decoder_refusals(pkg):
+    from toolbox_for_asr_and_tts_amd.decoder import ParaformerHead
+    cfg = po.DecoderConfig(num_blocks=1, vocab_size=300)
+    sd = po.make_state_dict(cfg, seed=16)
+    head = ParaformerHead(pkg.Context(), num_blocks=1, vocab_size=300)
+    with pytest.raises(ValueError):
+        head.workspace_bytes(1, 10, 11)                      # nothing loaded yet
+    bad = dict(sd)
+    del bad["decoder.decoders3.0.norm1.weight"]
+    with pytest.raises(pkg.AsrfeError, match="missing tensor decoder.decoders3.0.norm1.weight"):
+        head.load_state_dict(bad)
+    big = dict(sd)
+    big["decoder.decoders.0.feed_forward.w_1.weight"] = sd["decoder.decoders.0.feed_forward.w_1.weight"] * 1e5
+    with pytest.raises(pkg.AsrfeError, match="feed-forward hidden layer.*fp16 range"):
+        ParaformerHead(pkg.Context(), num_blocks=1, vocab_size=300).load_state_dict(big)
+    head.load_state_dict(sd)
+    with pytest.raises(pkg.AsrfeError, match="already loaded"):
+        head.load_state_dict(sd)
+    with pytest.raises(ValueError):
+        head.forward(torch.zeros(1, 10, 512), [10])          # host tensor
+
+
+def test_http_route_returns_the_heads_text(pkg):
+    """POST /api/v1/voice/asr with a ParaformerHead as the default decoder: success = true and the text is what the
+    head recognises on the engine's output for the clip."""
+    import base64
+    import importlib
+    import io
+    import wave
+    from fastapi.testclient import TestClient
+    from oracle import fbank_oracle as fo
+    from oracle import sanm_oracle as so
+    from toolbox_for_asr_and_tts_amd.decoder import ParaformerHead
+    svc = importlib.import_module("toolbox_for_asr_and_tts_amd.service")
+    pcm = fo.synth_pcm("bursts", 16000 * 2, 21)
+    buf = io.BytesIO()
+    with wave.open(buf, "wb") as wf:
+        wf.setnchannels(1)
+        wf.setsampwidth(2)
+        wf.setframerate(16000)
+        wf.writeframes(pcm.tobytes())
+    cfg_e = pkg.default_config()
+    cfg_e.enc_num_blocks = 2
+    eng = pkg.AsrEngine(batch=1, max_samples=16000 * 5, cfg=cfg_e, state_dict=so.make_state_dict(so.SanmConfig(num_blocks=2), seed=8))
+    cfg = po.DecoderConfig(num_blocks=2, vocab_size=300)
+    head = ParaformerHead(eng.ctx, num_blocks=2, vocab_size=300, token_list=[chr(0x4E00 + i) for i in range(300)])
+    head.load_state_dict(po.make_state_dict(cfg, seed=17))
+    out, olens = eng.run(torch.from_numpy(pcm[None]).cuda(), torch.tensor([pcm.size], dtype=torch.int32, device="cuda"))
+    want = head.recognize(out, olens)[0]
+    assert isinstance(want, str) and len(want) > 0
+    client = TestClient(svc.create_app(eng, head=head))
+    r = client.post("/api/v1/voice/asr", json={"audio_data": base64.b64encode(buf.getvalue()).decode(), "diagnosis_session_id": "t"})
+    assert r.status_code == 200 and r.json() == {"text": want, "success": True, "message": None, "sample_id": None}

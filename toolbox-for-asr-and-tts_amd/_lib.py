@@ -58,6 +58,20 @@ class Config(C.Structure):
     ]
 
 
+class DecoderConfig(C.Structure):
+    _fields_ = [
+        ("num_blocks", C.c_int32),
+        ("linear_units", C.c_int32),
+        ("kernel_size", C.c_int32),
+        ("vocab_size", C.c_int32),
+        ("ln_eps", C.c_float),
+        ("threshold", C.c_float),
+        ("tail_threshold", C.c_float),
+        ("smooth_factor", C.c_float),
+        ("noise_threshold", C.c_float),
+    ]
+
+
 PROF_KINDS = ["fbank", "frontend", "lfr_cmvn", "pe_table", "layernorm", "gemm_qkv", "fsmn", "attention", "gemm_out",
               "gemm_ffn1", "gemm_ffn2", "post_attn"]
 
@@ -95,6 +109,14 @@ SIGNATURES = {
                                           C.c_int32, C.c_void_p, C.c_int64, C.c_void_p]),
     "asrfe_encoder_forward_static": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p,
                                                  C.c_int32, C.c_void_p]),
+    "asrfe_default_decoder_config": (C.c_int32, [C.POINTER(DecoderConfig)]),
+    "asrfe_load_decoder_weights": (C.c_int32, [C.c_void_p, C.POINTER(DecoderConfig), C.POINTER(TensorDesc), C.c_int32]),
+    "asrfe_decoder_workspace_bytes": (C.c_int64, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32]),
+    "asrfe_decoder_logits_stride": (C.c_int32, [C.c_void_p]),
+    "asrfe_cif_predictor": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p,
+                                        C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
+    "asrfe_decoder_forward": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,
+                                          C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     "asrfe_host_mel_banks": (C.c_int32, [C.POINTER(Config), C.POINTER(C.c_double)]),
     "asrfe_host_window": (C.c_int32, [C.POINTER(Config), C.POINTER(C.c_double)]),
     "asrfe_profile_begin": (C.c_int32, [C.c_void_p, C.c_int32]),

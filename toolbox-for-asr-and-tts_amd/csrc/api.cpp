@@ -9,6 +9,7 @@
 #include "common.h"
 #include "encoder.h"
 #include "gemm.h"
+#include "weights.h"
 
 using namespace asrfe;
 
@@ -121,24 +122,6 @@ extern "C" int32_t asrfe_host_window(const asrfe_config* cfg, double* out /* [fr
     build_window(*cfg, v);
     std::memcpy(out, v.data(), v.size() * sizeof(double));
     return ASRFE_OK;
-}
-
-template <typename T>
-static int32_t upload(asrfe_ctx* ctx, const std::vector<T>& host, T** dev) {
-    void* p = nullptr;
-    HIP_TRY(ctx, hipMalloc(&p, std::max<size_t>(host.size() * sizeof(T), 16)));
-    ctx->owned.push_back(p);
-    HIP_TRY(ctx, hipMemcpy(p, host.data(), host.size() * sizeof(T), hipMemcpyHostToDevice));
-    *dev = static_cast<T*>(p);
-    return ASRFE_OK;
-}
-
-static uint16_t bf16_rne(float f) {
-    uint32_t u;
-    std::memcpy(&u, &f, 4);
-    if ((u & 0x7fffffffu) > 0x7f800000u) return static_cast<uint16_t>((u >> 16) | 0x40);  // NaN stays NaN
-    u += 0x7fffu + ((u >> 16) & 1u);
-    return static_cast<uint16_t>(u >> 16);
 }
 
 static int32_t check_config(const asrfe_config& c, std::string& why) {
@@ -323,6 +306,7 @@ extern "C" int32_t asrfe_profile_end(asrfe_ctx* ctx, asrfe_profile* out) {
 extern "C" int32_t asrfe_destroy(asrfe_ctx* ctx) {
     if (!ctx) return ASRFE_OK;
     for (hipEvent_t e : ctx->prof_events) (void)hipEventDestroy(e);
+    free_decoder(ctx);
     for (void* p : ctx->owned) (void)hipFree(p);
     delete ctx;
     return ASRFE_OK;
@@ -341,65 +325,6 @@ extern "C" int32_t asrfe_load_cmvn(asrfe_ctx* ctx, const float* shift, const flo
 }
 
 // ---- encoder weights ---------------------------------------------------------------------------
-struct HostTensor {
-    const float* data;
-    std::vector<int64_t> shape;
-    int64_t numel() const {
-        int64_t n = 1;
-        for (auto s : shape) n *= s;
-        return n;
-    }
-};
-
-static int32_t need(asrfe_ctx* ctx, const std::map<std::string, HostTensor>& m, const std::string& name,
-                    std::vector<int64_t> shape, const HostTensor** out) {
-    auto it = m.find(name);
-    if (it == m.end()) return set_err(ctx, ASRFE_ERR_NOT_LOADED, "asrfe_load_encoder_weights: missing tensor " + name);
-    if (it->second.shape != shape) return set_err(ctx, ASRFE_ERR_SHAPE, "asrfe_load_encoder_weights: bad shape for " + name);
-    *out = &it->second;
-    return ASRFE_OK;
-}
-
-static int32_t up_f32(asrfe_ctx* ctx, const HostTensor* t, float** dev) {
-    std::vector<float> v(t->data, t->data + t->numel());
-    return upload(ctx, v, dev);
-}
-
-static uint16_t f16_rne(float f) {
-    const _Float16 h = static_cast<_Float16>(f);
-    uint16_t u;
-    std::memcpy(&u, &h, 2);
-    return u;
-}
-
-// [n][k] float -> 16-bit [n][k_pad] (bf16 or fp16 per the context) with zero columns past k
-static int32_t up_bf16(asrfe_ctx* ctx, const HostTensor* t, int k_pad, uint16_t** dev) {
-    const int64_t n = t->shape[0], k = t->shape[1];
-    const bool f16 = ctx->cfg.enc_compute_dtype == ASRFE_DT_F16;
-    std::vector<uint16_t> v(static_cast<size_t>(n) * k_pad, 0);
-    for (int64_t r = 0; r < n; ++r)
-        for (int64_t c = 0; c < k; ++c) v[r * k_pad + c] = f16 ? f16_rne(t->data[r * k + c]) : bf16_rne(t->data[r * k + c]);
-    return upload(ctx, v, dev);
-}
-
-// A LayerNorm's scale and shift in front of a linear layer are folded into it:
-//     W (g * n + b) + c  =  (W diag(g)) n + (W b + c),        n = the normalised row,
-// so the LayerNorm kernels (and the fused feed-forward kernel) emit n without touching g and b.
-static void fold_layernorm(const HostTensor* w, const HostTensor* c, const HostTensor* g, const HostTensor* b,
-                           std::vector<float>& wf, std::vector<float>& cf) {
-    const int64_t n = w->shape[0], k = w->shape[1];
-    wf.resize(static_cast<size_t>(n * k));
-    cf.resize(static_cast<size_t>(n));
-    for (int64_t r = 0; r < n; ++r) {
-        double acc = c->data[r];
-        for (int64_t i = 0; i < k; ++i) {
-            wf[r * k + i] = w->data[r * k + i] * g->data[i];
-            acc += static_cast<double>(w->data[r * k + i]) * b->data[i];
-        }
-        cf[r] = static_cast<float>(acc);
-    }
-}
-
 // Wo [512][512], W1 [ff][512] and W2 [512][ff] as the piece stream of the fused post-attention kernel (16 KiB
 // LDS images in consumption order).  Four chunks of Wo come first: piece r of chunk c is
 // Wo[128 (r & 3) .. +128][64 (2 c + (r >> 2)) .. +64] as 128 rows of 128 bytes, 16-byte slot cs of row r holding
@@ -470,19 +395,6 @@ static int32_t up_layer_stream(asrfe_ctx* ctx, const HostTensor* wo, const HostT
 // q, k, v, the attention output (a convex combination of v rows), the FSMN memory (v plus 11 taps of v) and the
 // feed-forward hidden layer, and refuses weights whose bound passes the largest fp16 number: such a model needs
 // ASRFE_DT_BF16.  (The kernels additionally convert with saturation, so even then no infinity would arise.)
-constexpr double kF16Max = 65504.0;
-static double linear_bound(const std::vector<float>& w, const std::vector<float>& c, int64_t rows, int64_t k, int64_t r0,
-                           int64_t r1, std::vector<double>* per_row = nullptr) {
-    double worst = 0.0;
-    for (int64_t r = r0; r < r1 && r < rows; ++r) {
-        double ss = 0.0;
-        for (int64_t i = 0; i < k; ++i) ss += static_cast<double>(w[r * k + i]) * w[r * k + i];
-        const double b = std::sqrt(ss) * std::sqrt(static_cast<double>(k)) + std::fabs(static_cast<double>(c[r]));
-        if (per_row) (*per_row)[r - r0] = b;
-        worst = std::fmax(worst, b);
-    }
-    return worst;
-}
 static int32_t range_refusal(asrfe_ctx* ctx, int layer, const char* what, double bound) {
     char buf[256];
     std::snprintf(buf, sizeof(buf),
@@ -495,17 +407,8 @@ static int32_t range_refusal(asrfe_ctx* ctx, int layer, const char* what, double
 extern "C" int32_t asrfe_load_encoder_weights(asrfe_ctx* ctx, const asrfe_tensor_desc* descs, int32_t n) {
     if (!ctx || !descs || n <= 0) return set_err(ctx, ASRFE_ERR_BAD_ARG, "asrfe_load_encoder_weights: null argument");
     if (ctx->enc_loaded) return set_err(ctx, ASRFE_ERR_BAD_ARG, "asrfe_load_encoder_weights: weights already loaded");
-    std::map<std::string, HostTensor> m;
-    for (int i = 0; i < n; ++i) {
-        if (!descs[i].name || !descs[i].data_host || descs[i].ndim < 1 || descs[i].ndim > 4)
-            return set_err(ctx, ASRFE_ERR_BAD_ARG, "asrfe_load_encoder_weights: bad descriptor");
-        HostTensor t;
-        t.data = descs[i].data_host;
-        t.shape.assign(descs[i].shape, descs[i].shape + descs[i].ndim);
-        std::string name = descs[i].name;
-        if (name.rfind("encoder.", 0) == 0) name = name.substr(8);
-        m[name] = t;
-    }
+    TensorMap m;
+    if (int32_t rc0 = tensor_map(ctx, descs, n, "encoder.", "asrfe_load_encoder_weights", m)) return rc0;
     const asrfe_config& c = ctx->cfg;
     const int64_t d = c.enc_output_size, ff = c.enc_linear_units, ks = c.enc_kernel_size;
     ctx->layers.assign(c.enc_num_blocks, LayerWeights{});
@@ -721,11 +624,8 @@ extern "C" int32_t asrfe_debug_attention(asrfe_ctx* ctx, int32_t layer, const vo
     if (!ctx || !qkv || !lens || !att || !fsmn) return set_err(ctx, ASRFE_ERR_BAD_ARG, "asrfe_debug_attention: null argument");
     if (!ctx->enc_loaded) return set_err(ctx, ASRFE_ERR_NOT_LOADED, "asrfe_debug_attention: encoder weights not loaded");
     if (layer < 0 || layer >= ctx->cfg.enc_num_blocks) return set_err(ctx, ASRFE_ERR_BAD_ARG, "asrfe_debug_attention: no such layer");
-    AttnParams a{};
-    a.qkv = static_cast<const uint16_t*>(qkv); a.ld_qkv = 1536; a.lens = lens;
-    a.out = static_cast<uint16_t*>(att); a.ld_out = 512;
+    AttnParams a = attn_self(static_cast<const uint16_t*>(qkv), 1536, batch, tp, lens, static_cast<uint16_t*>(att), 512);
     a.fsmn = static_cast<uint16_t*>(fsmn); a.w_fsmn = ctx->layers[layer].w_fsmn;
-    a.B = batch; a.Tp = tp;
     a.scale_log2 = 1.4426950408889634f / std::sqrt(128.0f);
     a.flags = flags;
     return launch_attention(ctx, a, static_cast<hipStream_t>(stream));

@@ -58,17 +58,18 @@ __global__ __launch_bounds__(kAttnThreads, 2) void attn_kernel(const AttnParams 
     const int head = (logical / p.n_qtiles) & 3;
     const int b = logical / (p.n_qtiles * 4);
     int len = p.lens[b];
-    len = len < 0 ? 0 : (len > p.Tp ? p.Tp : len);
+    len = len < 0 ? 0 : (len > p.Tk ? p.Tk : len);
     const int qb = qtile * 128;          // first query row of the workgroup
     const int q0 = qb + wave * 32;       // first query row of the wave
-    const int64_t row0 = static_cast<int64_t>(b) * p.Tp;
+    const int64_t row0 = static_cast<int64_t>(b) * p.Tq;   // first query / output row of the utterance
+    const int64_t row0k = static_cast<int64_t>(b) * p.Tk;  // its first key / value row
     const int n_kt = (len + 63) >> 6;
-    const uint32_t ldb = static_cast<uint32_t>(p.ld_qkv) * 2;  // bytes per qkv row
+    const uint32_t ldb = static_cast<uint32_t>(p.ld_kv) * 2;  // bytes per key / value row
 
     // ---- tile staging: thread covers LDS slot (row i * 16 + (tid >> 4), chunk tid & 15) of a tile, i = 0..3
     const uint32_t smem_base = __builtin_amdgcn_readfirstlane(lds_addr_of(smem));
-    const char* kbase = reinterpret_cast<const char*>(p.qkv + row0 * p.ld_qkv + 512 + head * 128);
-    const char* vbase = reinterpret_cast<const char*>(p.qkv + row0 * p.ld_qkv + 1024 + head * 128);
+    const char* kbase = reinterpret_cast<const char*>(p.k + row0k * p.ld_kv + head * 128);
+    const char* vbase = reinterpret_cast<const char*>(p.v + row0k * p.ld_kv + head * 128);
     const int st_row = tid >> 4;
     const uint32_t k_chunk = (tid & 15) ^ ((tid >> 4) & 15);
     const uint32_t v_chunk = (tid & 15) ^ ((((tid >> 4) & 3) << 2) | ((tid >> 6) & 3));
@@ -77,7 +78,7 @@ __global__ __launch_bounds__(kAttnThreads, 2) void attn_kernel(const AttnParams 
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             int key = kt * 64 + i * 16 + st_row;
-            key = key < p.Tp ? key : p.Tp - 1;
+            key = key < p.Tk ? key : p.Tk - 1;
             const uint32_t ro = static_cast<uint32_t>(key) * ldb;
             lds_dma16(kbase, ro + k_chunk * 16, dst + i * 4096);
             if (with_v) lds_dma16(vbase, ro + v_chunk * 16, dst + kTileBytes + i * 4096);
@@ -91,7 +92,7 @@ __global__ __launch_bounds__(kAttnThreads, 2) void attn_kernel(const AttnParams 
     // running byte offsets (row i * 16 + st_row of the next tile; + 64 rows per tile) clamped to the last row:
     // no multiply and no burst of eight loads in front of the matrix work.
     const uint32_t tile_step = 64u * ldb;
-    const uint32_t last_row = static_cast<uint32_t>(p.Tp - 1) * ldb;
+    const uint32_t last_row = static_cast<uint32_t>(p.Tk - 1) * ldb;
     const uint32_t kclamp = last_row + k_chunk * 16, vclamp = last_row + v_chunk * 16;
     const uint32_t vdelta = (v_chunk - k_chunk) * 16;  // (wraps: added to a K offset it gives the V offset)
     uint32_t kro[4];
@@ -115,8 +116,8 @@ __global__ __launch_bounds__(kAttnThreads, 2) void attn_kernel(const AttnParams 
     u16x8 qf[8];
     {
         int qr = q0 + l31;
-        qr = qr < p.Tp ? qr : p.Tp - 1;
-        const uint16_t* qp = p.qkv + (row0 + qr) * p.ld_qkv + head * 128 + 8 * h;
+        qr = qr < p.Tq ? qr : p.Tq - 1;
+        const uint16_t* qp = p.q + (row0 + qr) * p.ld_q + head * 128 + 8 * h;
 #pragma unroll
         for (int s = 0; s < 8; ++s) qf[s] = *reinterpret_cast<const u16x8*>(qp + 16 * s);
     }
@@ -138,7 +139,7 @@ __global__ __launch_bounds__(kAttnThreads, 2) void attn_kernel(const AttnParams 
 #pragma unroll
         for (int i = 0; i < 9; ++i) {
             int t = qb - kFsmnHalo + i * 16 + st_row;
-            t = t < 0 ? 0 : (t > p.Tp - 1 ? p.Tp - 1 : t);
+            t = t < 0 ? 0 : (t > p.Tk - 1 ? p.Tk - 1 : t);
             lds_dma16(vbase, static_cast<uint32_t>(t) * ldb + (tid & 15) * 16, fst + i * 4096);
         }
         // the taps of the head's 128 channels: 11 rows of 512 bytes = 352 16-byte pieces, piece q = (tap q / 32,
@@ -186,7 +187,7 @@ __global__ __launch_bounds__(kAttnThreads, 2) void attn_kernel(const AttnParams 
             v2f acc = xw[(i + kFsmnHalo) % kFsmnTaps];
 #pragma unroll
             for (int j = 0; j < kFsmnTaps; ++j) acc = __builtin_elementwise_fma(wt[j], xw[(i + j) % kFsmnTaps], acc);
-            if (t < p.Tp) out[static_cast<int64_t>(i) * 256] = t < len ? pack_elem2<F16>(acc.x, acc.y) : 0u;
+            if (t < p.Tk) out[static_cast<int64_t>(i) * 256] = t < len ? pack_elem2<F16>(acc.x, acc.y) : 0u;
         }
         __syncthreads();
     };
@@ -239,7 +240,7 @@ __global__ __launch_bounds__(kAttnThreads, 2) void attn_kernel(const AttnParams 
         if (!(xf & 32)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (!(xf & 16)) __syncthreads();
         ATTN_STAMP();  // 0: past the barrier
-        if (!more && !(xf & 1)) fsmn_stage_issue();  // the last tile is in buffer 0: the stage's bytes are free
+        if (!more && !(xf & 1) && p.fsmn) fsmn_stage_issue();  // the last tile is in buffer 0: the stage's bytes are free
         ATTN_STAMP();  // 1: prefetch issued
         const char* ks = smem + ((xf & 8) ? 0 : cur) * kBufBytes;
         const char* vs = ks + kTileBytes;
@@ -376,19 +377,22 @@ __global__ __launch_bounds__(kAttnThreads, 2) void attn_kernel(const AttnParams 
         const int r = i * 4 + (lane >> 4), cch = lane & 15;
         const uint4 v = *reinterpret_cast<const uint4*>(es + r * 256 + ((cch ^ (r & 15)) << 4));
         const int qr = q0 + r;
-        if (qr < p.Tp) *reinterpret_cast<uint4*>(p.out + (row0 + qr) * p.ld_out + head * 128 + cch * 8) = v;
+        if (qr < p.Tq) *reinterpret_cast<uint4*>(p.out + (row0 + qr) * p.ld_out + head * 128 + cch * 8) = v;
     }
-    if (!(xf & 1)) fsmn_phase();
+    if (!(xf & 1) && p.fsmn) fsmn_phase();
 }
 
 int32_t launch_attention(asrfe_ctx* ctx, const AttnParams& p, hipStream_t s) {
-    if (p.B <= 0 || p.Tp <= 0) return ASRFE_OK;
-    if (!p.qkv || !p.lens || !p.out || !p.fsmn || !p.w_fsmn) return set_err(ctx, ASRFE_ERR_BAD_ARG, "attention: null argument");
+    if (p.B <= 0 || p.Tq <= 0 || p.Tk <= 0) return ASRFE_OK;
+    if (!p.q || !p.k || !p.v || !p.lens || !p.out || (p.fsmn && (!p.w_fsmn || p.Tq != p.Tk)))
+        return set_err(ctx, ASRFE_ERR_BAD_ARG, "attention: null argument (or an FSMN output with Tq != Tk)");
+    if (p.ld_q % 8 != 0 || p.ld_kv % 8 != 0 || p.ld_out % 8 != 0)
+        return set_err(ctx, ASRFE_ERR_BAD_ARG, "attention: row strides must be multiples of 8 elements");
     // (the kernel's running 32-bit load offsets run up to two tiles past the last row before they are clamped)
-    if ((static_cast<int64_t>(p.Tp) + 128) * p.ld_qkv * 2 >= (int64_t{1} << 32))
-        return set_err(ctx, ASRFE_ERR_SHAPE, "attention: one utterance's qkv rows must stay below 4 GiB");
+    if ((static_cast<int64_t>(p.Tk) + 128) * p.ld_kv * 2 >= (int64_t{1} << 32))
+        return set_err(ctx, ASRFE_ERR_SHAPE, "attention: one utterance's key / value rows must stay below 4 GiB");
     AttnParams q = p;
-    q.n_qtiles = (p.Tp + 127) / 128;
+    q.n_qtiles = (p.Tq + 127) / 128;
     dim3 grid(q.n_qtiles * 4 * p.B);
     if (ctx->cfg.enc_compute_dtype == ASRFE_DT_F16) hipLaunchKernelGGL(attn_kernel<true>, grid, dim3(kAttnThreads), 0, s, q);
     else hipLaunchKernelGGL(attn_kernel<false>, grid, dim3(kAttnThreads), 0, s, q);

@@ -102,10 +102,8 @@ int32_t encoder_forward(asrfe_ctx* ctx, const float* feats, const int32_t* lens,
         }
         qkv_ready = false;
 
-        AttnParams a{};
-        a.qkv = bf.qkv; a.ld_qkv = 1536; a.lens = lens; a.out = bf.att; a.ld_out = 512;
+        AttnParams a = attn_self(bf.qkv, 1536, B, Tp, lens, bf.att, 512);
         a.fsmn = bf.fsmn; a.w_fsmn = L.w_fsmn;
-        a.B = B; a.Tp = Tp;
         a.scale_log2 = 1.4426950408889634f / std::sqrt(128.0f);
         { ProfScope ps(ctx, PK_ATTN, s); rc = launch_attention(ctx, a, s); }
         if (rc) return rc;

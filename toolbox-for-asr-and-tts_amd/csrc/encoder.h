@@ -5,19 +5,33 @@
 
 namespace asrfe {
 
+// 4-head attention (d_k = 128) of Tq query rows per utterance onto Tk key / value rows per utterance, of which the
+// first lens[b] are valid.  Encoder self-attention: q, k, v are column blocks of one [B*Tp][1536] buffer (attn_self);
+// decoder cross-attention: q comes from the token rows, k and v from the projected encoder frames.
 struct AttnParams {
-    const uint16_t* qkv;  // 16-bit [B*Tp][ld_qkv]: q at column head*128, k at 512 + head*128, v at 1024 + head*128
-    int ld_qkv;
-    const int32_t* lens;  // [B]
-    uint16_t* out;        // 16-bit [B*Tp][ld_out] attention output
+    const uint16_t* q;    // 16-bit [B*Tq][ld_q], head h at columns h*128 .. +127
+    int ld_q, Tq;
+    const uint16_t* k;    // 16-bit [B*Tk][ld_kv], head h at columns h*128 .. +127 from this pointer
+    const uint16_t* v;    // same row stride as k
+    int ld_kv, Tk;
+    const int32_t* lens;  // [B] valid keys per utterance
+    uint16_t* out;        // 16-bit [B*Tq][ld_out] attention output
     int ld_out;
-    uint16_t* fsmn;       // 16-bit [B*Tp][512] FSMN memory block of v (rows t >= lens[b] zero)
-    const float* w_fsmn;  // f32 [11][512] taps, tap-major
-    int B, Tp;
+    uint16_t* fsmn;       // self-attention only (Tq == Tk), else null: 16-bit [B*Tk][512] FSMN memory block of v
+    const float* w_fsmn;  // f32 [11][512] taps, tap-major (with fsmn)
+    int B;
     int n_qtiles;         // filled by launch_attention
     float scale_log2;     // log2(e) / sqrt(d_k)
     int flags;            // timing experiments only (results are wrong when set)
 };
+// the encoder's layout: qkv [B*Tp][ld] = q | k | v
+inline AttnParams attn_self(const uint16_t* qkv, int ld, int B, int Tp, const int32_t* lens, uint16_t* out, int ld_out) {
+    AttnParams a{};
+    a.q = qkv; a.ld_q = ld; a.Tq = Tp;
+    a.k = qkv + 512; a.v = qkv + 1024; a.ld_kv = ld; a.Tk = Tp;
+    a.lens = lens; a.out = out; a.ld_out = ld_out; a.B = B;
+    return a;
+}
 int32_t launch_attention(asrfe_ctx* ctx, const AttnParams& p, hipStream_t s);
 
 // pe[t][i] = sin((t+1) inv[i]) for i < D/2, cos((t+1) inv[i - D/2]) otherwise

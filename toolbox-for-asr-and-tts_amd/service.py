@@ -114,10 +114,22 @@ def finalize_session(engine, session: StreamingPcmSession, decoder: Optional[Cal
     return decoder(out, out_lens) or ""
 
 
-def create_app(engine, decoder: Optional[Callable] = None, clock: Optional[Callable[[], float]] = None) -> FastAPI:
+def head_decoder(head) -> Callable:
+    """``decoder`` callable over a ``ParaformerHead`` (CIF predictor + decoder on the device): the utterance's text when
+    the head knows the model's token list, else its token ids joined by spaces."""
+    def decode(out, out_lens):
+        res = head.recognize(out, out_lens)[0]
+        return res if isinstance(res, str) else " ".join(str(t) for t in res)
+    return decode
+
+
+def create_app(engine, decoder: Optional[Callable] = None, clock: Optional[Callable[[], float]] = None, head=None) -> FastAPI:
     """``clock``: the time source of the streaming sessions' silence timer (``time.time`` by default).
     ``engine``: an ``AsrEngine(batch=1, max_samples=...)`` (anything with ``run``, ``device`` and
-    ``max_samples`` serves, which is how the CPU tests drive the route)."""
+    ``max_samples`` serves, which is how the CPU tests drive the route).  ``head``: a loaded ``ParaformerHead`` on the
+    engine's context; it becomes the decoder when no ``decoder`` callable is given."""
+    if decoder is None and head is not None:
+        decoder = head_decoder(head)
     app = FastAPI(title="voice")
     # The reference calls its models on the event-loop thread (voice.py:613, voice_interface.py:2049), which stalls
     # every other connection for the length of a recognition.  Here the engine runs on ONE worker thread: requests
