@@ -384,6 +384,31 @@ def main():
                                         "note": "enc_compute_dtype = ASRFE_DT_BF16, same step; parity 6e-2 instead of 1e-2"}}
         del eng_b
 
+        # (2c) the step behind the encoder (CIF predictor + 16-block decoder + arg-max, up to 256 tokens per clip) on the
+        #      encoder output of the headline step: its own time, and the rate of the whole chain PCM -> token ids
+        from toolbox_for_asr_and_tts_amd.decoder import ParaformerHead
+        from toolbox_for_asr_and_tts_amd.synth import decoder_state_dict
+        head = ParaformerHead(eng.ctx)
+        head.load_state_dict(decoder_state_dict(seed=1))
+        eng.run(pcm, lens)
+        r = head.forward(eng.out, eng.feat_lens, n_max=256)
+        torch.cuda.synchronize()
+        tok = r["token_num"].cpu().tolist()
+        t_head = timed(lambda: head.forward(eng.out, eng.feat_lens, n_max=256), max(2, args.steps // 2))
+
+        def step_text():
+            o, l = eng.run(pcm, lens)
+            head.forward(o, l, n_max=256)
+
+        t_text = timed(step_text, max(2, args.steps // 2))
+        result["with_decoder"] = {
+            "head_ms_per_step": 1e3 * t_head, "chain_ms_per_step": 1e3 * t_text, "chain_utt_per_s": args.batch / t_text,
+            "tokens_per_clip_mean": sum(tok) / len(tok), "n_max": 256,
+            "note": "CIF predictor + Paraformer decoder (16 blocks, vocabulary 8404, random-init weights) + arg-max behind the "
+                    "headline step; never part of `value`",
+        }
+        del head
+
         # (3) latency of ONE 3 s clip (the shape of the reference's own CPU-runnable case, BASELINE configs[0]): eager
         #     launches and the same step replayed from a captured HIP graph
         eng_1 = pkg.AsrEngine(batch=1, max_samples=48000, state_dict=sd)

@@ -45,3 +45,50 @@ def encoder_state_dict(num_blocks: int = 50, input_size: int = 560, d: int = 512
     sd["after_norm.weight"] = torch.ones(d)
     sd["after_norm.bias"] = torch.zeros(d)
     return sd
+
+
+def decoder_state_dict(num_blocks: int = 16, d: int = 512, ff: int = 2048, kernel: int = 11, vocab: int = 8404,
+                       seed: int = 1, std: float = 0.02, alpha_bias: float = -0.4):
+    """Random-init CIF predictor + Paraformer decoder under FunASR's ``state_dict`` names (``predictor.*``,
+    ``decoder.*``).  ``alpha_bias`` centres the firing weights near 0.4, i.e. about 200 tokens per 30 s clip."""
+    g = torch.Generator(device="cpu")
+    g.manual_seed(seed)
+
+    def rnd(*shape, s=std):
+        return torch.randn(*shape, generator=g, dtype=torch.float32) * s
+
+    sd = {
+        "predictor.cif_conv1d.weight": rnd(d, d, 3),
+        "predictor.cif_conv1d.bias": rnd(d),
+        "predictor.cif_output.weight": rnd(1, d, s=0.05),
+        "predictor.cif_output.bias": torch.full((1,), alpha_bias),
+    }
+
+    def ffn(p):
+        sd[f"{p}.norm1.weight"] = torch.ones(d)
+        sd[f"{p}.norm1.bias"] = torch.zeros(d)
+        sd[f"{p}.feed_forward.w_1.weight"] = rnd(ff, d)
+        sd[f"{p}.feed_forward.w_1.bias"] = rnd(ff)
+        sd[f"{p}.feed_forward.norm.weight"] = torch.ones(ff)
+        sd[f"{p}.feed_forward.norm.bias"] = torch.zeros(ff)
+        sd[f"{p}.feed_forward.w_2.weight"] = rnd(d, ff)
+
+    for i in range(num_blocks):
+        p = f"decoder.decoders.{i}"
+        ffn(p)
+        for nm in ("norm2", "norm3"):
+            sd[f"{p}.{nm}.weight"] = torch.ones(d)
+            sd[f"{p}.{nm}.bias"] = torch.zeros(d)
+        sd[f"{p}.self_attn.fsmn_block.weight"] = rnd(d, 1, kernel, s=0.1)
+        sd[f"{p}.src_attn.linear_q.weight"] = rnd(d, d)
+        sd[f"{p}.src_attn.linear_q.bias"] = rnd(d)
+        sd[f"{p}.src_attn.linear_k_v.weight"] = rnd(2 * d, d)
+        sd[f"{p}.src_attn.linear_k_v.bias"] = rnd(2 * d)
+        sd[f"{p}.src_attn.linear_out.weight"] = rnd(d, d)
+        sd[f"{p}.src_attn.linear_out.bias"] = rnd(d)
+    ffn("decoder.decoders3.0")
+    sd["decoder.after_norm.weight"] = torch.ones(d)
+    sd["decoder.after_norm.bias"] = torch.zeros(d)
+    sd["decoder.output_layer.weight"] = rnd(vocab, d, s=0.05)
+    sd["decoder.output_layer.bias"] = rnd(vocab, s=0.05)
+    return sd
