@@ -95,6 +95,10 @@ typedef struct asrfe_config {
     int32_t enc_compute_dtype; /* 16-bit type of the MFMA operands (weights, activations, P): ASRFE_DT_F16
                                   (default: meets the 1e-2 parity bar) or ASRFE_DT_BF16 (same MFMA rate, ~8x the
                                   rounding error); accumulation, residual stream, LayerNorm and softmax are fp32 */
+    int32_t enc_small_batch_rows; /* encoder calls of at most this many rows (batch * tp; one short utterance) run a
+                                  launch plan built for latency: every product is cut into 32 x 32 output tiles spread
+                                  over the chip (1024 by default; 0 switches it off and saves the row-major weight
+                                  copies it reads, ~316 MB for paraformer-large) */
 } asrfe_config;
 
 /* One named host tensor of an encoder state_dict (FunASR key names without the "encoder." prefix). */

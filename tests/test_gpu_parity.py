@@ -229,20 +229,27 @@ def test_bad_arguments_raise(pkg, fe):
 
 
 # ---- encoder ---------------------------------------------------------------------------------------
-def run_encoder(pkg, num_blocks, seed, feats, lens, out_dtype=torch.float32, compute_dtype="float16"):
+# Calls of up to enc_small_batch_rows rows (1024 by default) take the latency launch plan, larger ones the throughput
+# plan; the oracle tests below run the sizes they were written for under BOTH (0 switches the latency plan off).
+PLANS = [pytest.param(0, id="throughput-plan"), pytest.param(1024, id="latency-plan")]
+
+
+def run_encoder(pkg, num_blocks, seed, feats, lens, out_dtype=torch.float32, compute_dtype="float16", small_rows=None):
     cfg = so.SanmConfig(num_blocks=num_blocks)
     sd = so.make_state_dict(cfg, seed=seed, dtype=torch.float32)
-    enc = pkg.SANMEncoder(num_blocks=num_blocks, compute_dtype=compute_dtype)
+    enc = pkg.SANMEncoder(num_blocks=num_blocks, compute_dtype=compute_dtype, small_batch_rows=small_rows)
     enc.load_state_dict(sd)
     out, olens, _ = enc.forward(feats.to("cuda"), lens, out_dtype=out_dtype)
     torch.cuda.synchronize()
     return out, olens, sd, cfg
 
 
-def test_encoder_tiny_golden(pkg):
+@pytest.mark.parametrize("small_rows", PLANS)
+def test_encoder_tiny_golden(pkg, small_rows):
     g = np.load(os.path.join(GOLDEN, "encoder_tiny.npz"))
     feats = torch.from_numpy(g["feats"])
-    out, olens, _, _ = run_encoder(pkg, int(g["num_blocks"]), int(g["seed"]), feats, torch.from_numpy(g["lens"]))
+    out, olens, _, _ = run_encoder(pkg, int(g["num_blocks"]), int(g["seed"]), feats, torch.from_numpy(g["lens"]),
+                                   small_rows=small_rows)
     assert olens.cpu().tolist() == g["olens"].tolist()
     got = out.cpu().numpy()
     err = np.max(np.abs(got - g["out"]))
@@ -266,22 +273,24 @@ def test_encoder_bf16_mode(pkg):
     assert e <= ENC_TOL_BF16, e
 
 
-def test_encoder_one_layer_vs_oracle_various_lengths(pkg):
+@pytest.mark.parametrize("small_rows", PLANS)
+def test_encoder_one_layer_vs_oracle_various_lengths(pkg, small_rows):
     """Exercises the key mask, the FSMN edge handling and row tails: T' not a multiple of 64 / 128."""
     for tp, lens in [(1, [1]), (7, [7, 3]), (65, [65, 64, 1]), (130, [130, 77]), (200, [129, 200, 5, 64])]:
         feats = so.synth_feats(len(lens), tp, 560, seed=tp)
         lt = torch.tensor(lens, dtype=torch.int32)
-        out, olens, sd, cfg = run_encoder(pkg, 1, 5, feats, lt)
+        out, olens, sd, cfg = run_encoder(pkg, 1, 5, feats, lt, small_rows=small_rows)
         want, wl = so.encoder_forward(feats.double(), lt, {k: v.double() for k, v in sd.items()}, cfg)
         assert olens.cpu().tolist() == wl.tolist()
         err = float((out.cpu().double() - want).abs().max())
         assert err <= ENC_TOL, (tp, lens, err)
 
 
-def test_encoder_50_layers_probe(pkg):
+@pytest.mark.parametrize("small_rows", PLANS)
+def test_encoder_50_layers_probe(pkg, small_rows):
     g = np.load(os.path.join(GOLDEN, "encoder_probe_50l.npz"))
     feats = so.synth_feats(2, 96, 560, seed=int(g["feats_seed"]))
-    out, olens, _, _ = run_encoder(pkg, 50, int(g["seed"]), feats, torch.from_numpy(g["lens"]))
+    out, olens, _, _ = run_encoder(pkg, 50, int(g["seed"]), feats, torch.from_numpy(g["lens"]), small_rows=small_rows)
     got = out.cpu().numpy()
     assert np.isfinite(got).all()
     e0 = np.max(np.abs(got[0, [0, 1, 47, 95]] - g["rows_b0"]))
@@ -351,13 +360,14 @@ def _trained_like(sd, seed):
     return out
 
 
-def test_encoder_nontrivial_layernorm_parameters(pkg):
+@pytest.mark.parametrize("small_rows", PLANS)
+def test_encoder_nontrivial_layernorm_parameters(pkg, small_rows):
     """3 layers with random LayerNorm gamma / beta (including after_norm) against the oracle."""
     cfg = so.SanmConfig(num_blocks=3)
     sd = _trained_like(so.make_state_dict(cfg, seed=9, dtype=torch.float32), seed=10)
     lens = torch.tensor([150, 97, 128], dtype=torch.int32)
     feats = so.synth_feats(3, 150, 560, seed=33)
-    enc = pkg.SANMEncoder(num_blocks=3)
+    enc = pkg.SANMEncoder(num_blocks=3, small_batch_rows=small_rows)
     enc.load_state_dict(sd)
     out, olens, _ = enc.forward(feats.cuda(), lens)
     want, wl = so.encoder_forward(feats.double(), lens, {k: v.double() for k, v in sd.items()}, cfg)
@@ -366,8 +376,9 @@ def test_encoder_nontrivial_layernorm_parameters(pkg):
     assert err <= ENC_TOL, err
 
 
+@pytest.mark.parametrize("small_rows", PLANS)
 @pytest.mark.parametrize("ff", [256, 1280, 3072, 5888])
-def test_encoder_other_feed_forward_widths(pkg, ff):
+def test_encoder_other_feed_forward_widths(pkg, ff, small_rows):
     """linear_units other than 2048: the weight stream of the post-attention kernel has ff / 64 hidden chunks, and
     above 5632 units its LDS has no room for the fused QKV projection, so every layer launches its own (5888 takes
     that plan).  3 layers against the oracle."""
@@ -375,7 +386,8 @@ def test_encoder_other_feed_forward_widths(pkg, ff):
     sd = _trained_like(so.make_state_dict(cfg, seed=20 + ff, dtype=torch.float32), seed=21)
     lens = torch.tensor([70, 33, 129], dtype=torch.int32)
     feats = so.synth_feats(3, 129, 560, seed=5)
-    enc = pkg.SANMEncoder(num_blocks=3, linear_units=ff)
+    # (the latency plan takes linear_units in steps of 512 up to 3072: of these widths only 3072; the others fall back)
+    enc = pkg.SANMEncoder(num_blocks=3, linear_units=ff, small_batch_rows=small_rows)
     enc.load_state_dict(sd)
     out, olens, _ = enc.forward(feats.cuda(), lens)
     want, wl = so.encoder_forward(feats.double(), lens, {k: v.double() for k, v in sd.items()}, cfg)
@@ -430,19 +442,20 @@ def test_post_attention_kernel_vs_fp64(pkg):
 
 
 def test_fused_and_unfused_encoder_paths_agree(pkg, monkeypatch):
-    """Three launch plans for the same layers: the default (the post-attention kernel also projects the next layer's
-    q, k, v), ASRFE_SEPARATE_QKV=1 (it writes the normalised rows and every layer launches its own projection) and
-    ASRFE_UNFUSED_FFN=1 (separate LayerNorm / GEMM launches).  Each must meet the parity bar; they round to 16 bits
-    at different points, so among themselves they agree to 4e-3, not bit for bit."""
+    """Four launch plans for the same layers: the throughput plan (the post-attention kernel also projects the next
+    layer's q, k, v), ASRFE_SEPARATE_QKV=1 (it writes the normalised rows and every layer launches its own projection),
+    ASRFE_UNFUSED_FFN=1 (separate LayerNorm / GEMM launches) and the latency plan (32 x 32 output tiles, the default
+    at this size).  Each must meet the parity bar; they round to 16 bits at different points, so among themselves they
+    agree to 4e-3, not bit for bit."""
     cfg = so.SanmConfig(num_blocks=3)
     sd = _trained_like(so.make_state_dict(cfg, seed=12, dtype=torch.float32), seed=13)
     lens = torch.tensor([130, 77], dtype=torch.int32)
     feats = so.synth_feats(2, 130, 560, seed=8)
     outs = []
-    for unfused, separate in (("0", "0"), ("0", "1"), ("1", "0")):
+    for unfused, separate, small in (("0", "0", 0), ("0", "1", 0), ("1", "0", 0), ("0", "0", 1024)):
         monkeypatch.setenv("ASRFE_UNFUSED_FFN", unfused)
         monkeypatch.setenv("ASRFE_SEPARATE_QKV", separate)
-        enc = pkg.SANMEncoder(num_blocks=3)
+        enc = pkg.SANMEncoder(num_blocks=3, small_batch_rows=small)
         enc.load_state_dict(sd)
         out, _, _ = enc.forward(feats.cuda(), lens)
         outs.append(out.cpu())
@@ -451,6 +464,8 @@ def test_fused_and_unfused_encoder_paths_agree(pkg, monkeypatch):
         assert float((o - want).abs().max()) <= ENC_TOL
     assert float((outs[0] - outs[1]).abs().max()) <= 4e-3
     assert float((outs[0] - outs[2]).abs().max()) <= 4e-3
+    assert float((outs[0] - outs[3]).abs().max()) <= 4e-3
+    assert not torch.equal(outs[0], outs[3])  # the latency plan really is another sequence of kernels
 
 
 def test_engine_streams_give_identical_results(pkg):
@@ -821,3 +836,18 @@ def test_engine_step_replays_from_a_hip_graph(pkg):
     g.replay()
     torch.cuda.synchronize()
     assert torch.equal(eng.out, want)
+
+
+def test_latency_plan_row_limit_and_tile_edges(pkg):
+    """The latency plan at its edges: one row, a row count that is no multiple of 32, exactly the limit (latency plan)
+    and one clip more (throughput plan); every case against the oracle, 3 layers with trained-like LayerNorm parameters."""
+    cfg = so.SanmConfig(num_blocks=3)
+    sd = _trained_like(so.make_state_dict(cfg, seed=40, dtype=torch.float32), seed=41)
+    enc = pkg.SANMEncoder(num_blocks=3, small_batch_rows=256)
+    enc.load_state_dict(sd)
+    for b, tp, lens in [(1, 1, [1]), (1, 50, [50]), (3, 37, [37, 5, 36]), (2, 128, [128, 100]), (2, 129, [129, 64])]:
+        feats = so.synth_feats(b, tp, 560, seed=tp)
+        lt = torch.tensor(lens, dtype=torch.int32)
+        out, _, _ = enc.forward(feats.cuda(), lt)
+        want, _ = so.encoder_forward(feats.double(), lt, {k: v.double() for k, v in sd.items()}, cfg)
+        assert float((out.cpu().double() - want).abs().max()) <= ENC_TOL, (b, tp)

@@ -55,6 +55,7 @@ class Config(C.Structure):
         ("enc_sanm_shift", C.c_int32),
         ("enc_ln_eps", C.c_float),
         ("enc_compute_dtype", C.c_int32),
+        ("enc_small_batch_rows", C.c_int32),
     ]
 
 

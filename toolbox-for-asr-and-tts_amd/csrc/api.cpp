@@ -67,6 +67,7 @@ extern "C" int32_t asrfe_default_config(asrfe_config* c) {
     c->enc_sanm_shift = 0;
     c->enc_ln_eps = 1e-12f;
     c->enc_compute_dtype = ASRFE_DT_F16;
+    c->enc_small_batch_rows = 1024;
     return ASRFE_OK;
 }
 
@@ -141,6 +142,7 @@ static int32_t check_config(const asrfe_config& c, std::string& why) {
     if (c.enc_kernel_size != 11 || c.enc_sanm_shift != 0) { why = "only FSMN kernel 11 / shift 0 is built"; return ASRFE_ERR_BAD_ARG; }
     if (c.enc_input_size < 8 || c.enc_input_size > 640 || c.enc_input_size % 8 != 0) { why = "enc_input_size must be a multiple of 8 in 8..640"; return ASRFE_ERR_BAD_ARG; }
     if (c.enc_num_blocks < 1) { why = "enc_num_blocks must be >= 1"; return ASRFE_ERR_BAD_ARG; }
+    if (c.enc_small_batch_rows < 0 || c.enc_small_batch_rows > 8192) { why = "enc_small_batch_rows must be in 0..8192"; return ASRFE_ERR_BAD_ARG; }
     if (c.enc_compute_dtype != ASRFE_DT_F16 && c.enc_compute_dtype != ASRFE_DT_BF16) { why = "enc_compute_dtype must be ASRFE_DT_F16 or ASRFE_DT_BF16"; return ASRFE_ERR_BAD_ARG; }
     return ASRFE_OK;
 }
@@ -169,6 +171,8 @@ extern "C" int32_t asrfe_create(const asrfe_config* cfg, asrfe_ctx** out) {
         e = std::getenv("ASRFE_SEPARATE_QKV");
         ctx->separate_qkv = e && e[0] == '1';
     }
+    // the latency plan's second feed-forward product takes linear_units in 512-deep steps up to 3072
+    ctx->small_rows = (cfg->enc_linear_units % 512 == 0 && cfg->enc_linear_units <= 3072 && !ctx->unfused_ffn) ? cfg->enc_small_batch_rows : 0;
     ctx->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     ctx->after_g = ctx->after_b = ctx->pe_inv = nullptr;
     std::memset(&ctx->tab, 0, sizeof(ctx->tab));
@@ -430,7 +434,9 @@ extern "C" int32_t asrfe_load_encoder_weights(asrfe_ctx* ctx, const asrfe_tensor
     const bool check_range = c.enc_compute_dtype == ASRFE_DT_F16;
     // Row-major copies of a layer's matrices exist only for the launch plans that read them: the layer-0 projection
     // always, the other projections when a layer's stream does not carry the next layer's Wqkv (or ASRFE_SEPARATE_QKV=1),
-    // Wo / W1 / W2 only under ASRFE_UNFUSED_FFN=1.  The default plan reads everything else from the piece stream.
+    // and all of Wqkv / Wo / W1 / W2 for the small-batch plan (enc_small_batch_rows > 0) or under ASRFE_UNFUSED_FFN=1.
+    // The throughput plan reads everything else from the piece stream.
+    const bool row_major = ctx->unfused_ffn || ctx->small_rows > 0;
     for (int li = 0; li < c.enc_num_blocks; ++li) {
         const std::string p = li == 0 ? std::string("encoders0.0") : "encoders." + std::to_string(li - 1);
         const int kpad = li == 0 ? ctx->kin_pad : static_cast<int>(d);
@@ -448,7 +454,7 @@ extern "C" int32_t asrfe_load_encoder_weights(asrfe_ctx* ctx, const asrfe_tensor
             if (bv > kF16Max) return range_refusal(ctx, li, "v (and the attention output)", bv);
         }
         {
-            const bool prev_stream_has_it = li > 0 && ctx->layers[li - 1].stream_has_qkv && !ctx->separate_qkv && !ctx->unfused_ffn;
+            const bool prev_stream_has_it = li > 0 && ctx->layers[li - 1].stream_has_qkv && !ctx->separate_qkv && !row_major;
             const HostTensor view{wfold.data(), tw->shape};
             if (!prev_stream_has_it && (rc = up_bf16(ctx, &view, kpad, &L.w_qkv))) return rc;
             if ((rc = upload(ctx, cfold, &L.b_qkv))) return rc;
@@ -467,7 +473,7 @@ extern "C" int32_t asrfe_load_encoder_weights(asrfe_ctx* ctx, const asrfe_tensor
             if ((rc = upload(ctx, w, &L.w_fsmn))) return rc;
         }
         if ((rc = need(ctx, m, p + ".self_attn.linear_out.weight", {d, d}, &t))) return rc;
-        if (ctx->unfused_ffn && (rc = up_bf16(ctx, t, static_cast<int>(d), &L.w_out))) return rc;
+        if (row_major && (rc = up_bf16(ctx, t, static_cast<int>(d), &L.w_out))) return rc;
         const HostTensor* t_wo = t;
         if ((rc = need(ctx, m, p + ".self_attn.linear_out.bias", {d}, &t)) || (rc = up_f32(ctx, t, &L.b_out))) return rc;
         if ((rc = need(ctx, m, p + ".norm2.weight", {d}, &tg)) || (rc = need(ctx, m, p + ".norm2.bias", {d}, &tb)) ||
@@ -480,10 +486,10 @@ extern "C" int32_t asrfe_load_encoder_weights(asrfe_ctx* ctx, const asrfe_tensor
             const double bh = linear_bound(wfold, cfold, ff, d, 0, ff);
             if (bh > kF16Max) return range_refusal(ctx, li, "feed-forward hidden layer", bh);
         }
-        if (ctx->unfused_ffn && (rc = up_bf16(ctx, &w1view, static_cast<int>(d), &L.w_ffn1))) return rc;
+        if (row_major && (rc = up_bf16(ctx, &w1view, static_cast<int>(d), &L.w_ffn1))) return rc;
         if ((rc = upload(ctx, cfold, &L.b_ffn1))) return rc;
         if ((rc = need(ctx, m, p + ".feed_forward.w_2.weight", {d, ff}, &t))) return rc;
-        if (ctx->unfused_ffn && (rc = up_bf16(ctx, t, static_cast<int>(ff), &L.w_ffn2))) return rc;
+        if (row_major && (rc = up_bf16(ctx, t, static_cast<int>(ff), &L.w_ffn2))) return rc;
         if (d != 512 || ff % 64 != 0 || ff > 7168)
             return set_err(ctx, ASRFE_ERR_SHAPE, "asrfe_load_encoder_weights: the fused post-attention kernel needs d = 512 and linear_units a multiple of 64 up to 7168");
         {

@@ -51,8 +51,8 @@ Buffers carve(const asrfe_ctx* ctx, void* ws, int B, int Tp) {
     b.qkv = c.take<uint16_t>(M * 1536);
     b.fsmn = c.take<uint16_t>(M * 512);
     b.att = c.take<uint16_t>(M * 512);
-    // the hidden layer exists in memory only under ASRFE_UNFUSED_FFN=1
-    b.ffn = ctx->unfused_ffn ? c.take<uint16_t>(M * ctx->cfg.enc_linear_units) : nullptr;
+    // the hidden layer exists in memory only for the small-batch plan and under ASRFE_UNFUSED_FFN=1
+    b.ffn = (ctx->unfused_ffn || M <= ctx->small_rows) ? c.take<uint16_t>(M * ctx->cfg.enc_linear_units) : nullptr;
     b.pe = c.take<float>(static_cast<int64_t>(Tp) * ctx->cfg.enc_input_size);
     b.bytes = c.off;
     return b;
@@ -76,6 +76,20 @@ int32_t encoder_forward(asrfe_ctx* ctx, const float* feats, const int32_t* lens,
         ProfScope ps(ctx, PK_PE, s);
         if ((rc = launch_pe_table(ctx, ctx->pe_inv, Tp, c.enc_input_size, bf.pe, s))) return rc;
     }
+
+    // Small-batch plan (a few hundred rows: one short utterance): six launches per layer, each cut into 32 x 32 output
+    // tiles so that the layer's weights are spread over the whole chip instead of streaming through a handful of CUs
+    //     att, fsmn = attention(qkv);   x = (x +) fsmn + att Wo^T + b;   h = n(x);   f = relu(h W1^T + b1);
+    //     x += f W2^T + b2;   h = n(x);   qkv = h Wqkv^T + b  (next layer)
+    const bool small = ctx->small_rows > 0 && M <= ctx->small_rows;
+    auto sgemm = [&](const uint16_t* A, int lda, const uint16_t* Wt, int ldw, const float* bias, int N, int K, void* out_,
+                     int ldo, const uint16_t* add16, const float* add32, int epi, int kind) -> int32_t {
+        GemmParams g{};
+        g.A = A; g.lda = lda; g.W = Wt; g.ldw = ldw; g.bias = bias; g.M = M; g.N = N; g.K = K; g.out = out_; g.ldo = ldo;
+        g.add16 = add16; g.ld16 = 512; g.add32 = add32; g.ld32 = 512;
+        ProfScope ps(ctx, kind, s);
+        return launch_skinny_gemm(ctx, g, epi, s);
+    };
 
     bool qkv_ready = false;  // the previous layer's post-attention kernel already projected this layer's q, k, v
     for (int li = 0; li < c.enc_num_blocks; ++li) {
@@ -107,6 +121,27 @@ int32_t encoder_forward(asrfe_ctx* ctx, const float* feats, const int32_t* lens,
         a.scale_log2 = 1.4426950408889634f / std::sqrt(128.0f);
         { ProfScope ps(ctx, PK_ATTN, s); rc = launch_attention(ctx, a, s); }
         if (rc) return rc;
+
+        if (small) {
+            const LayerWeights* Ln = li + 1 < c.enc_num_blocks ? &ctx->layers[li + 1] : nullptr;
+            if ((rc = sgemm(bf.att, 512, L.w_out, 512, L.b_out, 512, 512, bf.x, 512, bf.fsmn, li == 0 ? nullptr : bf.x,
+                            EPI_F32_ADD, PK_GEMM_OUT)))
+                return rc;
+            { ProfScope ps(ctx, PK_LN, s); rc = launch_ln512(ctx, bf.x, nullptr, nullptr, c.enc_ln_eps, M, bf.h, s); }
+            if (rc) return rc;
+            if ((rc = sgemm(bf.h, 512, L.w_ffn1, 512, L.b_ffn1, ff, 512, bf.ffn, ff, nullptr, nullptr, EPI_BF16_RELU, PK_GEMM_FFN1)))
+                return rc;
+            if ((rc = sgemm(bf.ffn, ff, L.w_ffn2, ff, L.b_ffn2, 512, ff, bf.x, 512, nullptr, bf.x, EPI_F32_ADD, PK_GEMM_FFN2)))
+                return rc;
+            if (Ln) {
+                { ProfScope ps(ctx, PK_LN, s); rc = launch_ln512(ctx, bf.x, nullptr, nullptr, c.enc_ln_eps, M, bf.h, s); }
+                if (rc) return rc;
+                if ((rc = sgemm(bf.h, 512, Ln->w_qkv, 512, Ln->b_qkv, 1536, 512, bf.qkv, 1536, nullptr, nullptr, EPI_BF16, PK_GEMM_QKV)))
+                    return rc;
+                qkv_ready = true;
+            }
+            continue;
+        }
 
         if (!ctx->unfused_ffn) {
             // output projection + FSMN + residual, feed-forward, and the next layer's q, k, v (or, when the weight

@@ -30,5 +30,7 @@ struct GemmParams {
 
 int32_t launch_gemm(asrfe_ctx* ctx, const GemmParams& p, int epi, hipStream_t s);
 int32_t prepare_gemm(asrfe_ctx* ctx);  // per-device kernel attributes; called by asrfe_create
+// the same product for a few hundred rows at most (skinny.hip): N a multiple of 32, K a multiple of 512 up to 3072
+int32_t launch_skinny_gemm(asrfe_ctx* ctx, const GemmParams& p, int epi, hipStream_t s);
 
 }  // namespace asrfe

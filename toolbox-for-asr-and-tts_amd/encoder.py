@@ -27,7 +27,10 @@ class SANMEncoder:
     def __init__(self, input_size: int = 560, output_size: int = 512, attention_heads: int = 4,
                  linear_units: int = 2048, num_blocks: int = 50, kernel_size: int = 11, sanm_shfit: int = 0,
                  input_layer: str = "pe", normalize_before: bool = True, selfattention_layer_type: str = "sanm",
-                 compute_dtype: str = "float16", ctx: _lib.Context | None = None, **kwargs):
+                 compute_dtype: str = "float16", ctx: _lib.Context | None = None, small_batch_rows: int | None = None,
+                 **kwargs):
+        # small_batch_rows: calls of at most this many rows (batch * T') take the latency launch plan (library default
+        # 1024; 0 switches it off and saves the row-major weight copies it reads)
         if input_layer != "pe" or not normalize_before or selfattention_layer_type != "sanm":
             raise ValueError("SANMEncoder: only input_layer='pe', normalize_before=True, 'sanm' attention are built")
         if ctx is None:
@@ -40,6 +43,8 @@ class SANMEncoder:
             cfg.enc_kernel_size = kernel_size
             cfg.enc_sanm_shift = sanm_shfit
             cfg.enc_compute_dtype = _COMPUTE_DTYPES[compute_dtype]
+            if small_batch_rows is not None:
+                cfg.enc_small_batch_rows = int(small_batch_rows)
             ctx = _lib.Context(cfg)
         self.ctx = ctx
         self._input_size = input_size

@@ -14,9 +14,13 @@ from toolbox_for_asr_and_tts_amd.synth import bench_pcm, encoder_state_dict  # n
 
 def main():
     sd = encoder_state_dict(num_blocks=50, seed=0)
-    for batch, seconds in ((1, 3), (1, 10), (4, 5), (8, 10), (16, 30)):
+    small_rows = int(sys.argv[1]) if len(sys.argv) > 1 else None   # enc_small_batch_rows (default: the library's)
+    for batch, seconds in ((1, 3), (1, 10), (4, 5), (8, 10), (4, 30), (8, 30), (16, 30)):
         n = 16000 * seconds
-        eng = pkg.AsrEngine(batch=batch, max_samples=n, state_dict=sd)
+        cfg = pkg.default_config()
+        if small_rows is not None:
+            cfg.enc_small_batch_rows = small_rows
+        eng = pkg.AsrEngine(batch=batch, max_samples=n, state_dict=sd, cfg=cfg)
         pcm = torch.from_numpy(bench_pcm(batch, n, seed=5)).cuda()
         lens = torch.full((batch,), n, dtype=torch.int32, device="cuda")
         for _ in range(3):
