@@ -97,8 +97,9 @@ typedef struct asrfe_config {
                                   rounding error); accumulation, residual stream, LayerNorm and softmax are fp32 */
     int32_t enc_small_batch_rows; /* encoder calls of at most this many rows (batch * tp; one short utterance) run a
                                   launch plan built for latency: every product is cut into 32 x 32 output tiles spread
-                                  over the chip (1024 by default; 0 switches it off and saves the row-major weight
-                                  copies it reads, ~316 MB for paraformer-large) */
+                                  over the chip (2048 by default: measured faster than the throughput plan up to ~2400
+                                  rows; 0 switches it off and saves the row-major weight copies it reads, ~316 MB
+                                  for paraformer-large) */
 } asrfe_config;
 
 /* One named host tensor of an encoder state_dict (FunASR key names without the "encoder." prefix). */
@@ -206,6 +207,35 @@ int32_t asrfe_cif_predictor(asrfe_ctx* ctx, const float* enc_out, const int32_t*
 int32_t asrfe_decoder_forward(asrfe_ctx* ctx, const float* enc_out, const int32_t* lens, int32_t batch, int32_t tp,
                               const float* embeds, const int32_t* token_num, int32_t n_max, int32_t* token_ids,
                               float* logits, void* workspace, int64_t workspace_bytes, void* stream);
+
+/* ---- HiFi-GAN vocoder (mel spectrogram -> waveform) ---------------------------------------------------------------
+ * Stands in for the vocoder half of the reference's TTS pipeline call
+ * pipeline_instance(input=seg, voice=voice, forward_params=...) (tts-service/app/services/tts_service.py:617-625; the
+ * pipeline is modelscope's Sambert-HiFiGAN, tts_service.py:34-38, 164-177).  The acoustic model that turns text into
+ * the mel spectrogram is not part of this library.  Generator structure as published (conv_pre, per stage a transposed
+ * convolution and the mean of n_resblocks residual blocks of three dilated / plain convolution pairs, conv_post, tanh);
+ * every convolution runs on the matrix cores as an implicit GEMM. */
+typedef struct asrfe_vocoder_config {
+    int32_t n_mels;                   /* 80 (a multiple of 16) */
+    int32_t initial_channel;          /* 512; halves at every stage, must stay a multiple of 32 */
+    int32_t n_upsamples;              /* 4 (1..8) */
+    int32_t upsample_rates[8];        /* 8, 8, 2, 2: their product is the hop (samples per mel frame) */
+    int32_t upsample_kernels[8];      /* 16, 16, 4, 4: a multiple of the stride each, padding (k - stride) / 2 */
+    int32_t n_resblocks;              /* 3 residual blocks per stage (1..4) */
+    int32_t resblock_kernels[4];      /* 3, 7, 11 (odd) */
+    int32_t resblock_dilations[4][3]; /* 1, 3, 5 each */
+    float lrelu_slope;                /* 0.1 */
+    float final_slope;                /* 0.01: the leaky ReLU in front of conv_post */
+} asrfe_vocoder_config;
+int32_t asrfe_default_vocoder_config(asrfe_vocoder_config* cfg);
+/* Generator tensors (host float32) under the published names with weight norm removed: conv_pre.{weight,bias},
+ * ups.I.{weight,bias}, resblocks.J.convs1.K.{weight,bias}, resblocks.J.convs2.K.{weight,bias}, conv_post.{weight,bias}. */
+int32_t asrfe_load_vocoder_weights(asrfe_ctx* ctx, const asrfe_vocoder_config* cfg, const asrfe_tensor_desc* descs, int32_t n);
+int64_t asrfe_vocoder_workspace_bytes(const asrfe_ctx* ctx, int32_t batch, int32_t t_mel);
+int32_t asrfe_vocoder_hop(const asrfe_ctx* ctx);
+/* mel [B, n_mels, t_mel] float32 (device) -> wav [B, t_mel * hop] float32 in (-1, 1). */
+int32_t asrfe_vocoder_forward(asrfe_ctx* ctx, const float* mel, int32_t batch, int32_t t_mel, float* wav, void* workspace,
+                              int64_t workspace_bytes, void* stream);
 
 /* The same forward for callers that cannot allocate device memory (code under HIP graph capture, tight serving
  * loops, harnesses that forbid hipMalloc): no workspace argument.  No counterpart in the reference.  The scratch is a

@@ -27,7 +27,8 @@ Files written:
                                  token counts, embeddings, logits, arg-max ids (fp64 oracle)
 
 ``python tests/golden/make_golden.py full`` writes only the two full-size encoder fixtures (several minutes of CPU
-time), ``... decoder`` only the decoder fixture.
+time), ``... decoder`` only the decoder fixture, ``... vocoder`` only the vocoder fixture
+(vocoder_tiny.npz: HiFi-GAN generator with 128 channels and two stages, B=2, 16 mel frames: mel, waveform).
 """
 from __future__ import annotations
 
@@ -173,7 +174,24 @@ def decoder_goldens():
     print("decoder tiny: token_num", tn.tolist(), "logits", tuple(logits.shape))
 
 
+def vocoder_goldens():
+    """HiFi-GAN generator, tiny: 128 channels, two stages (4, 2), B = 2, 16 mel frames (fp64 oracle)."""
+    from oracle import hifigan_oracle as ho
+
+    cfg = ho.HifiganConfig(initial_channel=128, upsample_rates=(4, 2), upsample_kernels=(8, 4))
+    sd = {k: v.double() for k, v in ho.make_state_dict(cfg, seed=9).items()}
+    mel = torch.randn(2, 80, 16, generator=torch.Generator().manual_seed(10), dtype=torch.float32)
+    wav = ho.generator_forward(mel.double(), sd, cfg)
+    np.savez_compressed(os.path.join(OUT, "vocoder_tiny.npz"), mel=mel.numpy(), wav=wav.numpy().astype(np.float32),
+                        seed=np.int32(9), initial_channel=np.int32(128), rates=np.array([4, 2], np.int32),
+                        kernels=np.array([8, 4], np.int32))
+    print("vocoder tiny:", tuple(wav.shape), "abs max", float(wav.abs().max()))
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "vocoder":
+        vocoder_goldens()
+        return
     if len(sys.argv) > 1 and sys.argv[1] == "full":
         full_size_goldens()
         return

@@ -229,7 +229,7 @@ def test_bad_arguments_raise(pkg, fe):
 
 
 # ---- encoder ---------------------------------------------------------------------------------------
-# Calls of up to enc_small_batch_rows rows (1024 by default) take the latency launch plan, larger ones the throughput
+# Calls of up to enc_small_batch_rows rows (2048 by default) take the latency launch plan, larger ones the throughput
 # plan; the oracle tests below run the sizes they were written for under BOTH (0 switches the latency plan off).
 PLANS = [pytest.param(0, id="throughput-plan"), pytest.param(1024, id="latency-plan")]
 

@@ -1,0 +1,132 @@
+"""GPU parity of the HiFi-GAN generator (every convolution an implicit GEMM on the matrix cores), called through the C
+ABI, against the CPU oracle (oracle/hifigan_oracle.py, fp64): waveform within 1e-2 of the oracle's (samples lie in
+(-1, 1); 16-bit operands through up to 4 stages x 18 convolutions).  The reference holds no fixture for the vocoder
+(parity unpinned)."""
+import io
+import wave
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import hifigan_oracle as ho
+
+pytestmark = pytest.mark.gpu
+
+WAV_TOL = 1e-2
+
+
+@pytest.fixture(scope="module")
+def pkg():
+    import toolbox_for_asr_and_tts_amd as p
+
+    p.load()
+    return p
+
+
+def build(cfg, seed):
+    from toolbox_for_asr_and_tts_amd.vocoder import HiFiGANGenerator
+    sd = ho.make_state_dict(cfg, seed=seed)
+    gen = HiFiGANGenerator(n_mels=cfg.n_mels, initial_channel=cfg.initial_channel, upsample_rates=cfg.upsample_rates,
+                           upsample_kernels=cfg.upsample_kernels, resblock_kernels=cfg.resblock_kernels,
+                           resblock_dilations=cfg.resblock_dilations, lrelu_slope=cfg.lrelu_slope, final_slope=cfg.final_slope)
+    gen.load_state_dict(sd)
+    return gen, sd
+
+
+def check(gen, sd, cfg, mel):
+    want = ho.generator_forward(mel.double(), {k: v.double() for k, v in sd.items()}, cfg)
+    got = gen.forward(mel.cuda())
+    torch.cuda.synchronize()
+    assert got.shape == want.shape == (mel.shape[0], mel.shape[2] * cfg.hop)
+    assert bool(torch.isfinite(got).all())
+    err = float((got.cpu().double() - want).abs().max())
+    assert err <= WAV_TOL, err
+    assert float(want.abs().max()) > 0.05  # a signal, not silence
+    return err
+
+
+@pytest.mark.parametrize("cfg,t_mel", [
+    (ho.HifiganConfig(initial_channel=128, upsample_rates=(4, 2), upsample_kernels=(8, 4)), 37),       # two stages, odd length
+    (ho.HifiganConfig(initial_channel=256, upsample_rates=(5, 4, 2), upsample_kernels=(15, 8, 4),
+                      resblock_kernels=(3, 5), resblock_dilations=((1, 2, 4), (1, 3, 5))), 19),          # k = 3 u (three taps per phase)
+    (ho.HifiganConfig(), 24),                                                                            # the published V1 layout
+])
+def test_generator_matches_oracle(pkg, cfg, t_mel):
+    gen, sd = build(cfg, seed=3)
+    g = torch.Generator().manual_seed(t_mel)
+    mel = torch.randn(2, cfg.n_mels, t_mel, generator=g)
+    err = check(gen, sd, cfg, mel)
+    print(f"channels {cfg.initial_channel}, rates {cfg.upsample_rates}: max waveform error {err:.3e}")
+
+
+def test_generator_fixture(pkg):
+    import os
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "vocoder_tiny.npz"))
+    cfg = ho.HifiganConfig(initial_channel=int(g["initial_channel"]), upsample_rates=tuple(g["rates"].tolist()),
+                           upsample_kernels=tuple(g["kernels"].tolist()))
+    gen, _ = build(cfg, seed=int(g["seed"]))
+    got = gen.forward(torch.from_numpy(g["mel"]).cuda())
+    assert np.max(np.abs(got.cpu().numpy() - g["wav"])) <= WAV_TOL
+
+
+def test_generator_batch_128_properties(pkg):
+    """The batch size of the vocoder configuration (128): every item equals the same item run alone (bit for bit),
+    edge frames included; one item against the oracle."""
+    cfg = ho.HifiganConfig()
+    gen, sd = build(cfg, seed=5)
+    g = torch.Generator().manual_seed(9)
+    mel = torch.randn(128, 80, 12, generator=g)
+    wav = gen.forward(mel.cuda())
+    torch.cuda.synchronize()
+    assert wav.shape == (128, 12 * 256) and bool(torch.isfinite(wav).all())
+    for k in (0, 77, 127):
+        alone = gen.forward(mel[k:k + 1].cuda())
+        assert torch.equal(alone[0], wav[k])
+    want = ho.generator_forward(mel[77:78].double(), {k: v.double() for k, v in sd.items()}, cfg)
+    assert float((wav[77].cpu().double() - want[0]).abs().max()) <= WAV_TOL
+
+
+def test_weight_norm_pairs_and_wav_bytes(pkg):
+    """A state_dict with weight norm still in place loads to the same generator; wav_bytes is a 16-bit mono WAV image."""
+    from toolbox_for_asr_and_tts_amd.vocoder import HiFiGANGenerator
+    cfg = ho.HifiganConfig(initial_channel=128, upsample_rates=(4, 2), upsample_kernels=(8, 4))
+    sd = ho.make_state_dict(cfg, seed=6)
+    wn = {}
+    for k, v in sd.items():
+        if k.endswith(".weight"):
+            norm = v.flatten(1).norm(dim=1).reshape(-1, *([1] * (v.dim() - 1)))
+            wn["generator." + k[:-7] + ".weight_g"] = norm.clone()
+            wn["generator." + k[:-7] + ".weight_v"] = v * 3.0      # any positive multiple of the direction
+        else:
+            wn["generator." + k] = v
+    kw = dict(initial_channel=128, upsample_rates=(4, 2), upsample_kernels=(8, 4), sample_rate=16000)
+    a = HiFiGANGenerator(**kw).load_state_dict(sd)
+    b = HiFiGANGenerator(**kw).load_state_dict(wn)
+    mel = torch.randn(1, 80, 10, generator=torch.Generator().manual_seed(1)).cuda()
+    wa, wb = a.forward(mel), b.forward(mel)
+    assert float((wa - wb).abs().max()) <= 2e-3      # g v / ||v|| re-rounds the weights: not bit-identical
+    img = a.wav_bytes(wa[0])
+    with wave.open(io.BytesIO(img), "rb") as wf:
+        assert (wf.getnchannels(), wf.getsampwidth(), wf.getframerate(), wf.getnframes()) == (1, 2, 16000, 80)
+        pcm = np.frombuffer(wf.readframes(80), dtype=np.int16)
+    assert np.array_equal(pcm, (wa[0].cpu().clamp(-1, 1) * 32767).round().to(torch.int16).numpy())
+
+
+def test_vocoder_refusals(pkg):
+    from toolbox_for_asr_and_tts_amd.vocoder import HiFiGANGenerator
+    cfg = ho.HifiganConfig(initial_channel=128, upsample_rates=(4, 2), upsample_kernels=(8, 4))
+    sd = ho.make_state_dict(cfg, seed=7)
+    with pytest.raises(pkg.AsrfeError, match="multiple of its stride"):
+        HiFiGANGenerator(initial_channel=128, upsample_rates=(4, 2), upsample_kernels=(7, 4)).load_state_dict(sd)
+    with pytest.raises(pkg.AsrfeError, match="multiple of 32"):
+        HiFiGANGenerator(initial_channel=96, upsample_rates=(4, 2), upsample_kernels=(8, 4)).load_state_dict(sd)
+    bad = {k: v for k, v in sd.items() if k != "ups.1.bias"}
+    with pytest.raises(pkg.AsrfeError, match="missing tensor ups.1.bias"):
+        HiFiGANGenerator(initial_channel=128, upsample_rates=(4, 2), upsample_kernels=(8, 4)).load_state_dict(bad)
+    gen = HiFiGANGenerator(initial_channel=128, upsample_rates=(4, 2), upsample_kernels=(8, 4))
+    with pytest.raises(ValueError):
+        gen.workspace_bytes(1, 10)                               # nothing loaded
+    gen.load_state_dict(sd)
+    with pytest.raises(ValueError):
+        gen.forward(torch.zeros(1, 80, 10))                      # host tensor

@@ -73,6 +73,21 @@ class DecoderConfig(C.Structure):
     ]
 
 
+class VocoderConfig(C.Structure):
+    _fields_ = [
+        ("n_mels", C.c_int32),
+        ("initial_channel", C.c_int32),
+        ("n_upsamples", C.c_int32),
+        ("upsample_rates", C.c_int32 * 8),
+        ("upsample_kernels", C.c_int32 * 8),
+        ("n_resblocks", C.c_int32),
+        ("resblock_kernels", C.c_int32 * 4),
+        ("resblock_dilations", (C.c_int32 * 3) * 4),
+        ("lrelu_slope", C.c_float),
+        ("final_slope", C.c_float),
+    ]
+
+
 PROF_KINDS = ["fbank", "frontend", "lfr_cmvn", "pe_table", "layernorm", "gemm_qkv", "fsmn", "attention", "gemm_out",
               "gemm_ffn1", "gemm_ffn2", "post_attn"]
 
@@ -118,6 +133,12 @@ SIGNATURES = {
                                         C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     "asrfe_decoder_forward": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,
                                           C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
+    "asrfe_default_vocoder_config": (C.c_int32, [C.POINTER(VocoderConfig)]),
+    "asrfe_load_vocoder_weights": (C.c_int32, [C.c_void_p, C.POINTER(VocoderConfig), C.POINTER(TensorDesc), C.c_int32]),
+    "asrfe_vocoder_workspace_bytes": (C.c_int64, [C.c_void_p, C.c_int32, C.c_int32]),
+    "asrfe_vocoder_hop": (C.c_int32, [C.c_void_p]),
+    "asrfe_vocoder_forward": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_int64,
+                                          C.c_void_p]),
     "asrfe_host_mel_banks": (C.c_int32, [C.POINTER(Config), C.POINTER(C.c_double)]),
     "asrfe_host_window": (C.c_int32, [C.POINTER(Config), C.POINTER(C.c_double)]),
     "asrfe_profile_begin": (C.c_int32, [C.c_void_p, C.c_int32]),

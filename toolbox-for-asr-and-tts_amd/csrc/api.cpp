@@ -67,7 +67,7 @@ extern "C" int32_t asrfe_default_config(asrfe_config* c) {
     c->enc_sanm_shift = 0;
     c->enc_ln_eps = 1e-12f;
     c->enc_compute_dtype = ASRFE_DT_F16;
-    c->enc_small_batch_rows = 1024;
+    c->enc_small_batch_rows = 2048;
     return ASRFE_OK;
 }
 
@@ -311,6 +311,7 @@ extern "C" int32_t asrfe_destroy(asrfe_ctx* ctx) {
     if (!ctx) return ASRFE_OK;
     for (hipEvent_t e : ctx->prof_events) (void)hipEventDestroy(e);
     free_decoder(ctx);
+    free_vocoder(ctx);
     for (void* p : ctx->owned) (void)hipFree(p);
     delete ctx;
     return ASRFE_OK;

@@ -11,6 +11,7 @@
 
 namespace asrfe {
 struct DecoderWeights;  // decoder.h
+struct VocoderWeights;  // vocoder.h
 
 // ---- frontend geometry the kernels are built for -------------------------------------------
 constexpr int kFrameLen = 400;
@@ -87,6 +88,7 @@ struct asrfe_ctx {
     float* after_g;
     float* after_b;
     float* pe_inv;  // [input_size/2] inverse timescales of the sinusoidal position code
+    asrfe::VocoderWeights* voc = nullptr;  // HiFi-GAN generator weights (asrfe_load_vocoder_weights), else null
     asrfe::DecoderWeights* dec = nullptr;  // CIF predictor + decoder weights (asrfe_load_decoder_weights), else null
     std::vector<void*> owned;  // every device allocation, freed in asrfe_destroy
     // optional per-kernel event timing (asrfe_profile_begin / _end)
@@ -120,6 +122,7 @@ int32_t set_err(asrfe_ctx* ctx, int32_t code, const std::string& msg);
 int32_t launch_fbank(asrfe_ctx* ctx, const FbankParams& p, int pcm_dtype, bool fused, int out_dtype, hipStream_t s);
 int32_t launch_lfr_cmvn(asrfe_ctx* ctx, const float* logmel, const int32_t* n_frames, int batch, int t_max,
                         int tp_max, void* feats, int out_dtype, int32_t* lens_out, hipStream_t s);
+void free_vocoder(asrfe_ctx* ctx);  // vocoder.cpp
 void free_decoder(asrfe_ctx* ctx);  // decoder.cpp: drops the predictor / decoder weight table (device memory is in `owned`)
 int32_t prepare_static_scratch(asrfe_ctx* ctx);  // static_scratch.hip: device address of the library's scratch array
 int64_t encoder_workspace_bytes(const asrfe_ctx* ctx, int batch, int tp);

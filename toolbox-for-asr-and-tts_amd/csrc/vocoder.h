@@ -1,0 +1,58 @@
+// HiFi-GAN generator (mel -> waveform): weights held by the context, kernel parameter blocks and launchers.
+#pragma once
+
+#include <vector>
+
+#include "common.h"
+
+namespace asrfe {
+
+// One convolution as an implicit GEMM on the matrix cores: out[co][q] = sum over (tap, ci) of W[co][tap * Ci + ci] *
+// x[q + off0 + tap * dtap][ci], activations time-major with the channels contiguous ([B][T][C], 16-bit, already passed
+// through the leaky ReLU that precedes every convolution of the generator).  A transposed convolution of stride u is u
+// such products ("phases"): output sample u q + r - pad takes taps r, r + u, ... from inputs q, q - 1, ...
+struct ConvParams {
+    const uint16_t* x;     // [B][Tin][Ci]
+    const uint16_t* w;     // [phases][Co][taps * Ci]
+    const float* bias;     // [Co]
+    int B, Tin, Ci, Co, taps;
+    int off0, dtap;        // input time of tap j at position q: q + off0 + j * dtap (outside [0, Tin): zero)
+    int phases, q_count;   // positions per phase
+    int out_mul, out_add0, out_add_step;  // output time = q * out_mul + out_add0 + phase * out_add_step (outside [0, Tout): dropped)
+    int Tout;
+    float slope;           // leaky ReLU applied to what y16 receives
+    uint16_t* y16;         // optional [B][Tout][Co]: lrelu(result)
+    const float* res_in;   // optional [B][Tout][Co] f32 added to the result
+    float* res_out;        // optional [B][Tout][Co] f32: the result
+    float* sum_out;        // optional [B][Tout][Co] f32: sum_mode 1 stores the result, 2 adds it
+    int sum_mode;
+};
+
+struct VocConv {
+    uint16_t* w; float* bias;
+    int Ci, Co, k, dil;
+};
+struct VocoderWeights {
+    asrfe_vocoder_config cfg;
+    VocConv pre;
+    struct Stage {
+        uint16_t* up_w; float* up_b;  // [u][Co][(k / u) * Ci]
+        int Ci, Co, k, u;
+        std::vector<VocConv> c1, c2;  // per residual block j and pair m: index j * 3 + m
+    };
+    std::vector<Stage> stages;
+    float* post_w; float* post_b;     // conv_post as f32 [7][C_last], [1]
+    int c_last, hop;
+};
+
+int32_t launch_conv_mfma(asrfe_ctx* ctx, const ConvParams& p, hipStream_t s);
+// mel f32 [B][n_mels][T] -> 16-bit [B][T][n_mels]
+int32_t launch_mel_to_ntc(asrfe_ctx* ctx, const float* mel, int B, int n_mels, int T, uint16_t* out, hipStream_t s);
+// y16 = lrelu(sum * scale, slope), n elements
+int32_t launch_scale_act(asrfe_ctx* ctx, const float* sum, float scale, float slope, int64_t n, uint16_t* y16, hipStream_t s);
+// wav[b][t] = tanh(bias + sum over (tap < 7, ci) w[tap][ci] x[b][t + tap - 3][ci])
+int32_t launch_conv_post(asrfe_ctx* ctx, const uint16_t* x, const float* w, const float* bias, int B, int T, int C,
+                         float* wav, hipStream_t s);
+void free_vocoder(asrfe_ctx* ctx);
+
+}  // namespace asrfe

@@ -30,7 +30,7 @@ class SANMEncoder:
                  compute_dtype: str = "float16", ctx: _lib.Context | None = None, small_batch_rows: int | None = None,
                  **kwargs):
         # small_batch_rows: calls of at most this many rows (batch * T') take the latency launch plan (library default
-        # 1024; 0 switches it off and saves the row-major weight copies it reads)
+        # 2048; 0 switches it off and saves the row-major weight copies it reads)
         if input_layer != "pe" or not normalize_before or selfattention_layer_type != "sanm":
             raise ValueError("SANMEncoder: only input_layer='pe', normalize_before=True, 'sanm' attention are built")
         if ctx is None:
