@@ -409,6 +409,24 @@ def main():
         }
         del head
 
+        # (2d) the vocoder configuration (BASELINE.json configs[4]): HiFi-GAN generator, published V1 layout (80 mel ->
+        #      hop 256, i.e. 24 kHz at 93.75 frames per second), batch 128 of 1 s spectrograms, random-init weights
+        from toolbox_for_asr_and_tts_amd.synth import vocoder_flops, vocoder_state_dict
+        from toolbox_for_asr_and_tts_amd.vocoder import HiFiGANGenerator
+        voc = HiFiGANGenerator(ctx=eng.ctx, sample_rate=24000)
+        voc.load_state_dict(vocoder_state_dict(seed=2))
+        mel = torch.randn(128, 80, 94, device=dev)
+        t_voc = timed(lambda: voc.forward(mel), 5)
+        vfl = 128 * vocoder_flops(94)
+        result["vocoder"] = {
+            "workload": "HiFi-GAN generator (512 channels, rates 8-8-2-2, residual kernels 3-7-11), 128 x 94 mel frames -> 128 x 24064 samples",
+            "ms_per_batch": 1e3 * t_voc, "audio_s_per_s": 128 * 94 * 256 / 24000.0 / t_voc,
+            "roofline": {"bound": "mfma", "achieved": vfl / t_voc / 1e12, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": vfl / t_voc / 1e12 / MFMA_BF16_PEAK_TFLOPS, "traffic": None,
+                         "note": "all convolutions of one batch (implicit-GEMM FLOPs) over the whole forward's wall time"},
+        }
+        del voc, mel
+
         # (3) latency of ONE 3 s clip (the shape of the reference's own CPU-runnable case, BASELINE configs[0]): eager
         #     launches and the same step replayed from a captured HIP graph
         eng_1 = pkg.AsrEngine(batch=1, max_samples=48000, state_dict=sd)

@@ -1,11 +1,11 @@
 // GEMM for a handful of rows (one short utterance: tens to a few hundred rows) on gfx950.
 //
 // The throughput kernels give a wave 32 rows and ALL output columns, so a layer costs the same ~140 us for 50 rows as
-// for 8000.  Here the work is cut the other way: a wave computes one 32-row x 32-column output tile over a 512-deep
-// slice of K, with both operands read straight from global memory (the activations are tiny and sit in L2, every
-// weight element is needed by exactly one column tile), all 32 k-steps of both operands requested before the first
-// MFMA: one memory round trip per launch instead of a pipelined stream.  N / 32 column tiles (x row-tile groups)
-// workgroups spread a layer's few MB of weights over the whole chip.
+// for 8000.  Here the work is cut the other way: a wave computes one 32-row x 32-column output tile over a slice of K,
+// with both operands read straight from global memory (the activations are tiny and sit in L2, every weight element
+// is needed by exactly one column tile), every k-step of both operands requested before the first MFMA: one memory
+// round trip per launch instead of a pipelined stream.  N / 32 column tiles (x row-tile groups) workgroups spread a
+// layer's few MB of weights over the whole chip.
 //
 //   A wave's K slice is 256 deep (16 k-steps: 128 registers of operands, all in flight at once); the KS = K / 256 waves
 //   that share an output tile sum their partial tiles through LDS in a fixed order.  K = 512 packs two row tiles (RT)

@@ -92,3 +92,50 @@ def decoder_state_dict(num_blocks: int = 16, d: int = 512, ff: int = 2048, kerne
     sd["decoder.output_layer.weight"] = rnd(vocab, d, s=0.05)
     sd["decoder.output_layer.bias"] = rnd(vocab, s=0.05)
     return sd
+
+
+V1_RATES, V1_KERNELS, V1_RES_KERNELS = (8, 8, 2, 2), (16, 16, 4, 4), (3, 7, 11)
+
+
+def vocoder_state_dict(initial_channel: int = 512, n_mels: int = 80, rates=V1_RATES, kernels=V1_KERNELS,
+                       res_kernels=V1_RES_KERNELS, seed: int = 2):
+    """Random-init HiFi-GAN generator (published V1 layout by default) under its ``state_dict`` names, weight norm
+    removed; scaled so that activations keep unit scale through the stack."""
+    g = torch.Generator(device="cpu")
+    g.manual_seed(seed)
+
+    def rnd(*shape, fan_in):
+        return torch.randn(*shape, generator=g, dtype=torch.float32) * (1.0 / fan_in) ** 0.5
+
+    sd = {"conv_pre.weight": rnd(initial_channel, n_mels, 7, fan_in=n_mels * 7), "conv_pre.bias": rnd(initial_channel, fan_in=16.0)}
+    ch = initial_channel
+    for i, (u, k) in enumerate(zip(rates, kernels)):
+        co = ch // 2
+        sd[f"ups.{i}.weight"] = rnd(ch, co, k, fan_in=ch * k / u)
+        sd[f"ups.{i}.bias"] = rnd(co, fan_in=16.0)
+        for j, rk in enumerate(res_kernels):
+            p = f"resblocks.{i * len(res_kernels) + j}"
+            for m in range(3):
+                for c in ("convs1", "convs2"):
+                    sd[f"{p}.{c}.{m}.weight"] = rnd(co, co, rk, fan_in=co * rk * 4)
+                    sd[f"{p}.{c}.{m}.bias"] = rnd(co, fan_in=64.0)
+        ch = co
+    sd["conv_post.weight"] = rnd(1, ch, 7, fan_in=ch * 7)
+    sd["conv_post.bias"] = rnd(1, fan_in=16.0)
+    return sd
+
+
+def vocoder_flops(t_mel: int, initial_channel: int = 512, n_mels: int = 80, rates=V1_RATES, kernels=V1_KERNELS,
+                  res_kernels=V1_RES_KERNELS) -> float:
+    """Multiply-add FLOPs (2 per MAC) of one item's convolutions: conv_pre, the transposed convolutions, the residual
+    blocks (six convolutions per block) and conv_post."""
+    fl = 2.0 * t_mel * initial_channel * n_mels * 7
+    ch, t = initial_channel, t_mel
+    for u, k in zip(rates, kernels):
+        co = ch // 2
+        t *= u
+        fl += 2.0 * t * co * ch * (k // u)
+        for rk in res_kernels:
+            fl += 6 * 2.0 * t * co * co * rk
+        ch = co
+    return fl + 2.0 * t * ch * 7
