@@ -63,7 +63,8 @@ def test_encoder_50_blocks_full_length_golden(pkg):
 def test_bench_batch_64x30s_matches_oracle_fixture(pkg):
     """The step bench.py times (AsrEngine, batch 64, 480000 samples per clip, 50 blocks, the benchmark's PCM and
     weights, two streams): clips 0, 31 and 63 against the fp64 oracle chain (features <= 1e-3, encoder rows <= 1e-2,
-    column sums), every output finite, and the same three clips run as a batch of 3 give the same rows (<= 1e-5):
+    column sums), every output finite, and the same three clips run as a batch of 3 give the same rows (<= 1e-5 under
+    the same launch plan, within the encoder tolerance under the latency plan a call of 1500 rows takes by default):
     a clip's result does not depend on the batch around it, so the fixture speaks for all 64."""
     from toolbox_for_asr_and_tts_amd.synth import bench_pcm, encoder_state_dict
     g = np.load(os.path.join(GOLDEN, "bench_clips_50l.npz"))
@@ -90,11 +91,19 @@ def test_bench_batch_64x30s_matches_oracle_fixture(pkg):
     out1 = eng.run_single_stream(dev(pcm), lens)[0]
     torch.cuda.synchronize()
     assert torch.equal(out1[clips].cpu(), torch.from_numpy(got))
-    # the three clips alone
-    eng3 = pkg.AsrEngine(batch=3, max_samples=SAMPLES, state_dict=sd)
+    # the three clips alone, under the same (throughput) launch plan: the same rows
+    from toolbox_for_asr_and_tts_amd import _lib
+    cfg0 = _lib.default_config()
+    cfg0.enc_small_batch_rows = 0
+    eng3 = pkg.AsrEngine(batch=3, max_samples=SAMPLES, cfg=cfg0, state_dict=sd)
     out3, _ = eng3.run(dev(pcm[clips]), lens[:3])
     torch.cuda.synchronize()
     assert float((out3.cpu() - torch.from_numpy(got)).abs().max()) <= 1e-5
+    # and as the library runs 1500 rows by default (the latency plan: another summation order), against the fixture
+    eng3l = pkg.AsrEngine(batch=3, max_samples=SAMPLES, state_dict=sd)
+    out3l = eng3l.run(dev(pcm[clips]), lens[:3])[0].cpu().numpy()
+    assert np.max(np.abs(out3l[:, rows] - g["out_rows"])) <= ENC_TOL
+    assert np.max(np.abs(out3l - got)) <= ENC_TOL
 
 
 def test_fbank_256x30s(pkg):
