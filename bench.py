@@ -88,6 +88,21 @@ def mfma_pipe_busy(kernel):
     return None if k is None else k["busy_frac_of_kernel_cycles"]
 
 
+def fbank_units():
+    """LDS / vector-ALU busy fractions of the fbank kernel from the newest committed counter pass of this build
+    (profiles/r*_fbank_units.json, tools/make_fbank_units_json.py); None if there is none."""
+    import glob
+    from tools.buildtag import csrc_tag
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_fbank_units.json")))
+    if not files:
+        return None
+    d = json.load(open(files[-1]))
+    if d.get("csrc_tag") != csrc_tag():
+        return None
+    d["file"] = os.path.relpath(files[-1], ROOT)
+    return d
+
+
 def cpu_model():
     try:
         for line in open("/proc/cpuinfo"):
@@ -558,6 +573,17 @@ def main():
             "bytes_per_launch": fb * FBANK_BYTES_PER_UTT,
             "utt_per_s": fb / (us * 1e-6),
         }
+        fu = fbank_units() if fb == 256 else None
+        if fu is not None:
+            # the kernel is bound by the LDS and the vector ALU, not by HBM: what it could reach with its busiest unit
+            # saturated, as it is and with the mel gather's bank conflicts gone (profile-time fractions, this run's rate)
+            result["roofline_fbank"]["practical_ceiling"] = {
+                "lds_busy_frac": fu["lds_busy_frac"], "lds_bank_conflict_frac": fu["lds_bank_conflict_frac"],
+                "valu_busy_frac": fu["valu_busy_frac"],
+                "ceiling_gbps_as_is": gbps * fu["speedup_bound_as_is"],
+                "ceiling_gbps_without_bank_conflicts": gbps * fu["speedup_bound_without_bank_conflicts"],
+                "ceiling_frac_of_hbm_peak": gbps * fu["speedup_bound_without_bank_conflicts"] / HBM_PEAK_GBPS,
+                "source": fu["file"]}
         del pcm_f, logmel
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

@@ -85,6 +85,7 @@ extern "C" int32_t asrfe_load_vocoder_weights(asrfe_ctx* ctx, const asrfe_vocode
     TensorMap m;
     int32_t rc;
     if ((rc = tensor_map(ctx, descs, n, "", kVocWho, m))) return rc;
+    if ((rc = prepare_conv(ctx))) return rc;
     VocoderWeights* W = new VocoderWeights();
     W->cfg = c;
     W->hop = hop;

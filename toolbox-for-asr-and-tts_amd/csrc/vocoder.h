@@ -26,6 +26,8 @@ struct ConvParams {
     float* res_out;        // optional [B][Tout][Co] f32: the result
     float* sum_out;        // optional [B][Tout][Co] f32: sum_mode 1 stores the result, 2 adds it
     int sum_mode;
+    int ci_tile;           // input channels staged per pass (filled by launch_conv_mfma)
+    int flags;             // timing experiments (ASRFE_VOC_ABLATE): 1 no stores, 2 no k-steps, 4 no activation staging, 8 no residual load
 };
 
 struct VocConv {
@@ -46,6 +48,7 @@ struct VocoderWeights {
 };
 
 int32_t launch_conv_mfma(asrfe_ctx* ctx, const ConvParams& p, hipStream_t s);
+int32_t prepare_conv(asrfe_ctx* ctx);  // per-device kernel attributes; called by asrfe_load_vocoder_weights
 // mel f32 [B][n_mels][T] -> 16-bit [B][T][n_mels]
 int32_t launch_mel_to_ntc(asrfe_ctx* ctx, const float* mel, int B, int n_mels, int T, uint16_t* out, hipStream_t s);
 // y16 = lrelu(sum * scale, slope), n elements

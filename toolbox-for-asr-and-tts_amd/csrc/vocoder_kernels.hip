@@ -2,6 +2,7 @@
 // matrix cores, plus the memory-bound pieces around them (input layout change, stage average, output convolution).
 #include "common.h"
 #include "elem.h"
+#include "lds_dma.h"
 #include "vocoder.h"
 
 namespace asrfe {
@@ -15,60 +16,199 @@ __device__ __forceinline__ float from_elem(uint16_t u) {
 __device__ __forceinline__ float lrelu(float v, float slope) { return v > 0.0f ? v : v * slope; }
 }  // namespace
 
-// One wave = 32 output channels x 32 positions; a workgroup = 4 waves = 128 consecutive positions of one channel tile,
-// one batch item and one phase.  Both operands come straight from global memory: the weight rows of a channel tile are
-// shared by every position tile (L2), the activation rows by the taps that overlap them (L1).  MFMA operand layout:
-// lane (l31, h) holds 8 consecutive k = 8 consecutive input channels of one tap, of weight row l31 (A) and of position
-// l31 (B); accumulator register 4 g + e is output channel 8 g + 4 h + e of position l31.
-template <bool F16>
-__global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvParams p) {
+// Convolution tile kernel.  A workgroup (4 waves) owns NC * 32 output channels x 4 * NP * 32 positions of one batch item
+// and one phase; wave w owns positions [w * NP * 32, (w + 1) * NP * 32) as NC x NP accumulator tiles of 32 x 32.
+//
+//   Activations: the input rows the tile's taps touch (positions + (taps - 1) * |dtap| rows, at most 128 channels at a
+//   time) are staged once in LDS, zero outside [0, Tin); rows are padded by 16 bytes so that the 32 rows of an operand
+//   fragment fall in distinct banks.  Every tap reads its fragments from there at a row offset: no activation byte is
+//   fetched from memory twice by a workgroup, whatever the kernel width and dilation.
+//   Weights: streamed through an LDS ring in groups of GS k-steps (16 GS consecutive k of every output channel of the
+//   tile; 16-byte chunks swizzled by row so that a fragment read covers all banks) by LDS-DMA loads, three groups
+//   ahead; one counted wait + barrier per group.  Every workgroup of a launch reads the same weight rows: fetched once
+//   per workgroup and far ahead, they arrive from L2 without the latency of a hot line showing up in the loop.
+//   Accumulators start from bias + residual (loaded while the activations are staged), so the epilogue only stores.
+//   Per k-step (16 input channels of one tap) a wave issues NC * NP MFMAs on NC weight and NP activation fragments.
+// MFMA operand layout: lane (l31, h) holds 8 consecutive k = 8 consecutive input channels of one tap, of weight row l31
+// (A) and of position l31 (B); accumulator register 4 g + e is output channel 8 g + 4 h + e of position l31.
+constexpr int kConvRingSlots = 4;
+template <int NC>
+constexpr int conv_group_steps() { return NC == 4 ? 2 : 4; }  // a ring slot is NC * 32 rows x 32 GS bytes: 8 KiB at most
+
+template <bool F16, int NC, int NP, int OCC>
+__global__ __launch_bounds__(256, OCC) void conv_tile_kernel(const ConvParams p) {
+    extern __shared__ __attribute__((aligned(16))) char xs[];
     saturate_fp16_conversions<F16>();
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    constexpr int P = 4 * NP * 32;
+    constexpr int NSLOT = kConvRingSlots;
+    constexpr int GS = conv_group_steps<NC>();
+    constexpr int kRowBytes = 32 * GS;              // one output channel's k of a group
+    constexpr int kSlotBytes = NC * 32 * kRowBytes;
+    constexpr int kCpr = 2 * GS;                    // 16-byte chunks per ring row
+    constexpr int kRowsPerInstr = 64 / kCpr;        // rows one LDS-DMA instruction (1 KiB) covers
+    constexpr int kInstrPerWave = NC * 32 / kRowsPerInstr / 4;
+    constexpr int kSwzShift = GS == 4 ? 1 : 2;      // rows sharing a 256-byte bank line: 2 (128-byte rows) or 4
+    constexpr int NSTG = (OCC == 1 && NP <= 3) ? 16 : 8;        // 16-byte activation chunks a thread keeps in flight while staging
+    static_assert(kInstrPerWave >= 1, "ring geometry");
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, h = lane >> 5;
     const int b = blockIdx.z / p.phases, ph = blockIdx.z - b * p.phases;
-    const int co0 = blockIdx.y * 32;
-    const int q = blockIdx.x * 128 + wave * 32 + l31;
+    const int co0 = blockIdx.y * (NC * 32);
+    const int q0 = blockIdx.x * P;
+    const int span = (p.taps - 1) * (p.dtap < 0 ? -p.dtap : p.dtap);
+    const int lo = p.off0 + (p.dtap < 0 ? (p.taps - 1) * p.dtap : 0);  // smallest input offset of any tap
+    const int R = P + span;
+    const int CiT = p.ci_tile, nblk = CiT >> 4, cpr = CiT >> 3;  // channels per pass, k-steps per tap, 16-byte chunks per row
+    const int stride = 2 * CiT + 16;
     const int K = p.taps * p.Ci;
-    const uint16_t* wrow = p.w + (static_cast<int64_t>(ph) * p.Co + co0 + l31) * K + 8 * h;
-    const uint16_t* xb = p.x + static_cast<int64_t>(b) * p.Tin * p.Ci + 8 * h;
-    f32x16 acc;
+    const int S = p.taps * nblk;
+    const int G = (S + GS - 1) / GS;
+    const int zero_at = R * stride;
+    const int ring_at = (zero_at + 16 + 127) & ~127;
+    const uint32_t ring_lds = __builtin_amdgcn_readfirstlane(lds_addr_of(xs) + ring_at);
+    // the sum over a stage's residual blocks can ride in the accumulator too when nothing else is stored
+    const bool fold_sum = p.sum_mode == 2 && !p.res_out && !p.y16;
+
+    // ---- accumulators = bias (+ residual) (+ running sum): requested first, needed at the first MFMA
+    f32x16 acc[NC][NP];
 #pragma unroll
-    for (int e = 0; e < 16; ++e) acc[e] = 0.0f;
-    const int nblk = p.Ci >> 4;
-    for (int tap = 0; tap < p.taps; ++tap) {
-        const int ti = q + p.off0 + tap * p.dtap;
-        const bool ok = ti >= 0 && ti < p.Tin;
-        const uint16_t* xr = xb + static_cast<int64_t>(ok ? ti : 0) * p.Ci;
-        const uint16_t* wr = wrow + tap * p.Ci;
-        for (int cb = 0; cb < nblk; ++cb) {
-            u16x8 xf = *reinterpret_cast<const u16x8*>(xr + 16 * cb);
-            if (!ok) xf = u16x8{0, 0, 0, 0, 0, 0, 0, 0};
-            const u16x8 wf = *reinterpret_cast<const u16x8*>(wr + 16 * cb);
-            acc = mfma32<F16>(wf, xf, acc);
+    for (int np = 0; np < NP; ++np) {
+        const int q = q0 + wave * (NP * 32) + np * 32 + l31;
+        const int to = q * p.out_mul + p.out_add0 + ph * p.out_add_step;
+        const bool ok = q < p.q_count && to >= 0 && to < p.Tout;
+        const int64_t orow = (static_cast<int64_t>(b) * p.Tout + (ok ? to : 0)) * p.Co + co0 + 4 * h;
+#pragma unroll
+        for (int nc = 0; nc < NC; ++nc)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                float4 v = *reinterpret_cast<const float4*>(p.bias + co0 + nc * 32 + 8 * g + 4 * h);
+                if (p.res_in && ok && !(p.flags & 8)) {
+                    const float4 t = *reinterpret_cast<const float4*>(p.res_in + orow + nc * 32 + 8 * g);
+                    v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
+                }
+                if (fold_sum && ok) {
+                    const float4 t = *reinterpret_cast<const float4*>(p.sum_out + orow + nc * 32 + 8 * g);
+                    v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
+                }
+                acc[nc][np][4 * g] = v.x; acc[nc][np][4 * g + 1] = v.y; acc[nc][np][4 * g + 2] = v.z; acc[nc][np][4 * g + 3] = v.w;
+            }
+    }
+
+    // weight staging: instruction w + 4 i of a group (i < kInstrPerWave) moves ring rows kRowsPerInstr (w + 4 i) ...;
+    // this lane's row of instruction w and the source chunk that belongs in its slot
+    const uint16_t* wtile = p.w + (static_cast<int64_t>(ph) * p.Co + co0) * K;
+    const int srow = kRowsPerInstr * wave + lane / kCpr;             // + 4 kRowsPerInstr i
+    const int schunk = (lane & (kCpr - 1)) ^ ((srow >> kSwzShift) & (kCpr - 1));
+    const int wsw = (l31 >> kSwzShift) & (kCpr - 1);                 // swizzle of the fragment rows nc * 32 + l31
+
+    const uint16_t* xitem = p.x + static_cast<int64_t>(b) * p.Tin * p.Ci;
+    for (int ci0 = 0; ci0 < p.Ci; ci0 += CiT) {
+        if (ci0) {  // every wave is done with the previous pass's rows and ring, and no load into the ring is pending
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+        }
+        int gtap = 0, gcb = 0;  // first k-step of the next group to stage
+        auto issue = [&](int slot) {
+            const int kofs = gtap * p.Ci + ci0 + gcb * 16;
+            const int ce = min(kofs + 8 * schunk, K - 8);  // (a group may reach past the last k: those steps meet zeros)
+            const uint32_t dst = __builtin_amdgcn_readfirstlane(ring_lds + slot * kSlotBytes + wave * 1024);
+#pragma unroll
+            for (int i = 0; i < kInstrPerWave; ++i)
+                lds_dma16(wtile, static_cast<uint32_t>((srow + 4 * kRowsPerInstr * i) * K + ce) * 2u, dst + i * 4096);
+            gcb += GS;
+            while (gcb >= nblk) { gcb -= nblk; ++gtap; }
+            gtap = min(gtap, p.taps);  // (groups past the end keep re-reading the last valid chunk)
+        };
+#pragma unroll
+        for (int i = 0; i < NSLOT - 1; ++i) issue(i);
+
+        // ---- stage rows [q0 + lo, q0 + lo + R) x channels [ci0, ci0 + CiT)
+        const int n_chunks = R * cpr;
+        for (int i0 = tid; i0 < ((p.flags & 4) ? 0 : n_chunks); i0 += NSTG * 256) {
+            uint4 v[NSTG];
+            int dst[NSTG];
+#pragma unroll
+            for (int u = 0; u < NSTG; ++u) {
+                const int i = i0 + u * 256;
+                const int r = i / cpr, c = i - r * cpr;
+                const int ti = q0 + lo + r;
+                dst[u] = i < n_chunks ? r * stride + c * 16 : -1;
+                v[u] = make_uint4(0, 0, 0, 0);
+                if (i < n_chunks && ti >= 0 && ti < p.Tin)
+                    v[u] = *reinterpret_cast<const uint4*>(xitem + static_cast<int64_t>(ti) * p.Ci + ci0 + 8 * c);
+            }
+#pragma unroll
+            for (int u = 0; u < NSTG; ++u)
+                if (dst[u] >= 0) *reinterpret_cast<uint4*>(xs + dst[u]) = v[u];
+        }
+        if (tid == 0) *reinterpret_cast<uint4*>(xs + zero_at) = make_uint4(0, 0, 0, 0);
+        __syncthreads();
+
+        // ---- k-steps s = tap * nblk + cb in groups of GS; a step past the last one multiplies by the zero chunk
+        const int xbase = (wave * (NP * 32) + l31 + p.off0 - lo) * stride + h * 16;
+        int tap = 0, cb = 0;    // the k-step the next activation read belongs to
+        auto read_x = [&](u16x8 (&dst)[NP]) {
+            const bool real = tap < p.taps;
+            const int at = real ? xbase + tap * p.dtap * stride + cb * 32 : zero_at;
+            const int step = real ? 32 * stride : 0;
+#pragma unroll
+            for (int np = 0; np < NP; ++np) dst[np] = *reinterpret_cast<const u16x8*>(xs + at + np * step);
+            if (++cb == nblk) { cb = 0; ++tap; }
+        };
+        auto read_w = [&](u16x8 (&dst)[NC], int slot, int j) {
+            const char* wp = xs + ring_at + slot * kSlotBytes + l31 * kRowBytes + (((2 * j + h) ^ wsw) << 4);
+#pragma unroll
+            for (int nc = 0; nc < NC; ++nc) dst[nc] = *reinterpret_cast<const u16x8*>(wp + nc * 32 * kRowBytes);
+        };
+        u16x8 xf[2][NP], wf[2][NC];
+        read_x(xf[0]);
+        int slot = 0;
+        for (int g = 0; g < ((p.flags & 2) ? 0 : G); ++g) {
+            // this wave's part of group g has landed (the younger groups may still fly), then all waves meet: group g
+            // is complete and nobody reads group g - 1 any more, whose slot takes group g + NSLOT - 1
+            asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"((NSLOT - 2) * kInstrPerWave) : "memory");
+            issue(slot == 0 ? NSLOT - 1 : slot - 1);
+            read_w(wf[0], slot, 0);
+#pragma unroll
+            for (int j = 0; j < GS; ++j) {
+                read_x(xf[(j + 1) & 1]);
+                if (j + 1 < GS) read_w(wf[(j + 1) & 1], slot, j + 1);
+                __builtin_amdgcn_sched_barrier(0);  // the next step's fragment reads stay ahead of this step's MFMAs
+#pragma unroll
+                for (int nc = 0; nc < NC; ++nc)
+#pragma unroll
+                    for (int np = 0; np < NP; ++np) acc[nc][np] = mfma32<F16>(wf[j & 1][nc], xf[j & 1][np], acc[nc][np]);
+            }
+            slot = slot + 1 == NSLOT ? 0 : slot + 1;
         }
     }
-    const int to = q * p.out_mul + p.out_add0 + ph * p.out_add_step;
-    if (q >= p.q_count || to < 0 || to >= p.Tout) return;
-    const int64_t orow = (static_cast<int64_t>(b) * p.Tout + to) * p.Co + co0 + 4 * h;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the ring's last (unused) groups
+
+    // ---- epilogue: stores (a lane owns one position and, per accumulator tile, 4 x 4 channels)
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-        const int64_t o = orow + 8 * g;
-        const float4 b4 = *reinterpret_cast<const float4*>(p.bias + co0 + 8 * g + 4 * h);
-        float v0 = acc[4 * g] + b4.x, v1 = acc[4 * g + 1] + b4.y, v2 = acc[4 * g + 2] + b4.z, v3 = acc[4 * g + 3] + b4.w;
-        if (p.res_in) {
-            const float4 r = *reinterpret_cast<const float4*>(p.res_in + o);
-            v0 += r.x; v1 += r.y; v2 += r.z; v3 += r.w;
-        }
-        if (p.res_out) *reinterpret_cast<float4*>(p.res_out + o) = make_float4(v0, v1, v2, v3);
-        if (p.sum_mode == 1) {
-            *reinterpret_cast<float4*>(p.sum_out + o) = make_float4(v0, v1, v2, v3);
-        } else if (p.sum_mode == 2) {
-            const float4 t = *reinterpret_cast<const float4*>(p.sum_out + o);
-            *reinterpret_cast<float4*>(p.sum_out + o) = make_float4(t.x + v0, t.y + v1, t.z + v2, t.w + v3);
-        }
-        if (p.y16)
-            *reinterpret_cast<uint2*>(p.y16 + o) = make_uint2(pack_elem2<F16>(lrelu(v0, p.slope), lrelu(v1, p.slope)),
-                                                              pack_elem2<F16>(lrelu(v2, p.slope), lrelu(v3, p.slope)));
+    for (int np = 0; np < NP; ++np) {
+        const int q = q0 + wave * (NP * 32) + np * 32 + l31;
+        const int to = q * p.out_mul + p.out_add0 + ph * p.out_add_step;
+        if (q >= p.q_count || to < 0 || to >= p.Tout || ((p.flags & 1) && acc[0][np][0] != 12345.0f)) continue;
+        const int64_t orow = (static_cast<int64_t>(b) * p.Tout + to) * p.Co + co0 + 4 * h;
+#pragma unroll
+        for (int nc = 0; nc < NC; ++nc)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int64_t o = orow + nc * 32 + 8 * g;
+                const float v0 = acc[nc][np][4 * g], v1 = acc[nc][np][4 * g + 1], v2 = acc[nc][np][4 * g + 2], v3 = acc[nc][np][4 * g + 3];
+                if (p.res_out) *reinterpret_cast<float4*>(p.res_out + o) = make_float4(v0, v1, v2, v3);
+                if (p.sum_mode == 1 || fold_sum) {
+                    *reinterpret_cast<float4*>(p.sum_out + o) = make_float4(v0, v1, v2, v3);
+                } else if (p.sum_mode == 2) {
+                    const float4 t = *reinterpret_cast<const float4*>(p.sum_out + o);
+                    *reinterpret_cast<float4*>(p.sum_out + o) = make_float4(t.x + v0, t.y + v1, t.z + v2, t.w + v3);
+                }
+                if (p.y16)
+                    *reinterpret_cast<uint2*>(p.y16 + o) = make_uint2(pack_elem2<F16>(lrelu(v0, p.slope), lrelu(v1, p.slope)),
+                                                                      pack_elem2<F16>(lrelu(v2, p.slope), lrelu(v3, p.slope)));
+            }
     }
 }
 
@@ -120,14 +260,90 @@ __global__ __launch_bounds__(256) void conv_post_kernel(const uint16_t* __restri
         if (e__ != hipSuccess) return set_err(ctx, ASRFE_ERR_HIP, std::string(who " launch: ") + hipGetErrorString(e__)); \
     } while (0)
 
-int32_t launch_conv_mfma(asrfe_ctx* ctx, const ConvParams& p, hipStream_t s) {
+namespace {
+constexpr int kConvLdsMax = 160 * 1024;
+
+// Tile shapes: NC = output-channel tiles per workgroup (1, 2 or 4, by the channel count), NP = position tiles per wave,
+// OCC = workgroups a CU holds at once.  With 128 channels and more the product is MFMA-bound and the largest tile wins
+// (fewest operand bytes per MFMA); with fewer channels a convolution is bound by its activation traffic, and two
+// workgroups per CU let one load and store while the other computes.
+struct ConvShape { int np, occ; };
+// activation rows + zero chunk (rounded up to 128 bytes) + weight ring
+int64_t conv_lds_bytes(int rows, int stride, int nc) {
+    return ((static_cast<int64_t>(rows) * stride + 16 + 127) & ~int64_t{127}) + kConvRingSlots * nc * 32 * 32 * (nc == 4 ? 2 : 4);
+}
+constexpr int kMaxShapes = 5;
+const ConvShape kShapes[3][kMaxShapes] = {{{8, 2}, {4, 2}, {2, 2}, {1, 2}, {0, 0}},   // NC = 1
+                                          {{4, 2}, {2, 2}, {1, 2}, {0, 0}, {0, 0}},   // NC = 2
+                                          {{2, 2}, {4, 1}, {3, 1}, {2, 1}, {1, 1}}};  // NC = 4
+
+template <bool F16>
+const void* conv_fn(int nc, int np, int occ) {
+#define CF(NCV, NPV, OCCV) if (nc == NCV && np == NPV && occ == OCCV) return reinterpret_cast<const void*>(conv_tile_kernel<F16, NCV, NPV, OCCV>)
+    CF(4, 2, 2); CF(4, 1, 1); CF(4, 2, 1); CF(4, 3, 1); CF(4, 4, 1);
+    CF(2, 1, 2); CF(2, 2, 2); CF(2, 4, 2);
+    CF(1, 1, 2); CF(1, 2, 2); CF(1, 4, 2); CF(1, 8, 2);
+#undef CF
+    return nullptr;
+}
+// channels per pass: all of them up to 128; beyond that 128 or 64 at a time (a group of k-steps must not straddle two
+// taps unless the pass covers every channel).  Two workgroups per CU only fit with 64.
+int conv_ci_tile(int ci, int nc, int occ) {
+    if (nc == 4 && occ == 2) return ci <= 64 ? ci : (ci % 64 == 0 ? 64 : 0);
+    return ci <= 128 ? ci : (ci % 128 == 0 ? 128 : (ci % 64 == 0 ? 64 : 0));
+}
+}  // namespace
+
+// The dynamic-LDS limit of a kernel is a per-device attribute: called with the context's device current when the
+// vocoder weights are loaded.
+int32_t prepare_conv(asrfe_ctx* ctx) {
+    for (int f16 = 0; f16 < 2; ++f16)
+        for (int nci = 0; nci < 3; ++nci)
+            for (int k = 0; k < kMaxShapes; ++k) {
+                const int nc = 1 << nci, np = kShapes[nci][k].np, occ = kShapes[nci][k].occ;
+                if (!np) continue;
+                const void* fn = f16 ? conv_fn<true>(nc, np, occ) : conv_fn<false>(nc, np, occ);
+                if (!fn || hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, kConvLdsMax / occ) != hipSuccess)
+                    return set_err(ctx, ASRFE_ERR_HIP, "vocoder convolution: cannot raise the dynamic LDS limit");
+            }
+    return ASRFE_OK;
+}
+
+int32_t launch_conv_mfma(asrfe_ctx* ctx, const ConvParams& pin, hipStream_t s) {
+    ConvParams p = pin;
     if (p.B <= 0 || p.q_count <= 0) return ASRFE_OK;
     if (p.Ci % 16 != 0 || p.Co % 32 != 0 || p.taps < 1 || p.phases < 1 || !p.x || !p.w || !p.bias)
         return set_err(ctx, ASRFE_ERR_SHAPE, "vocoder convolution: input channels must be a multiple of 16, output channels of 32");
     if (static_cast<int64_t>(p.B) * p.phases > 65535) return set_err(ctx, ASRFE_ERR_SHAPE, "vocoder convolution: batch * stride too large");
-    const dim3 grid((p.q_count + 127) / 128, p.Co / 32, p.B * p.phases), block(256);
-    if (ctx->cfg.enc_compute_dtype == ASRFE_DT_F16) hipLaunchKernelGGL(conv_mfma_kernel<true>, grid, block, 0, s, p);
-    else hipLaunchKernelGGL(conv_mfma_kernel<false>, grid, block, 0, s, p);
+    if (p.taps * p.Ci < 8) return set_err(ctx, ASRFE_ERR_SHAPE, "vocoder convolution: too few weights");
+    static const int ablate = [] { const char* e = getenv("ASRFE_VOC_ABLATE"); return e ? atoi(e) : 0; }();
+    p.flags = ablate & 15;
+    const int nci = p.Co % 128 == 0 ? 2 : (p.Co % 64 == 0 ? 1 : 0), nc = 1 << nci;
+    const int span = (p.taps - 1) * (p.dtap < 0 ? -p.dtap : p.dtap);
+    // positions per workgroup: the first shape of the list that fits in its share of the LDS and wastes under a tenth
+    // of its positions, else the one wasting least
+    int pick = -1, best = -1;
+    double best_eff = -1.0;
+    for (int k = 0; k < kMaxShapes; ++k) {
+        const int cand = kShapes[nci][k].np, occ = kShapes[nci][k].occ, P = 128 * cand;
+        if (!cand || ((ablate & 16) && nc == 4 && occ == 2)) continue;
+        const int cit = conv_ci_tile(p.Ci, nc, occ);
+        if (!cit || conv_lds_bytes(P + span, 2 * cit + 16, nc) > kConvLdsMax / occ) continue;
+        const int tiles = (p.q_count + P - 1) / P;
+        const double eff = static_cast<double>(p.q_count) / (static_cast<double>(tiles) * P);
+        if (eff >= 0.9) { pick = k; break; }
+        if (eff > best_eff) { best_eff = eff; best = k; }
+    }
+    if (pick < 0) pick = best;
+    if (pick < 0) return set_err(ctx, ASRFE_ERR_SHAPE, "vocoder convolution: channel count or kernel width x dilation not supported");
+    const int np = kShapes[nci][pick].np, occ = kShapes[nci][pick].occ, P = 128 * np;
+    p.ci_tile = conv_ci_tile(p.Ci, nc, occ);
+    const unsigned lds = static_cast<unsigned>(conv_lds_bytes(P + span, 2 * p.ci_tile + 16, nc));
+    const dim3 grid((p.q_count + P - 1) / P, p.Co / (32 * nc), p.B * p.phases), block(256);
+    const bool f16 = ctx->cfg.enc_compute_dtype == ASRFE_DT_F16;
+    const void* fn = f16 ? conv_fn<true>(nc, np, occ) : conv_fn<false>(nc, np, occ);
+    void* args[1] = {&p};
+    if (hipLaunchKernel(fn, grid, block, args, lds, s) != hipSuccess) { /* reported below */ }
     VOC_CHECK_LAUNCH("vocoder convolution");
     return ASRFE_OK;
 }
