@@ -60,6 +60,24 @@ def test_generator_matches_oracle(pkg, cfg, t_mel):
     print(f"channels {cfg.initial_channel}, rates {cfg.upsample_rates}: max waveform error {err:.3e}")
 
 
+@pytest.mark.parametrize("cfg,t_mel", [
+    # one second of the published layout: 752 / 6016 / 12032 / 24064 positions per stage, i.e. every tile shape the
+    # vocoder configuration runs with, many position tiles per item (taps reaching across tile borders, dilation 5)
+    (ho.HifiganConfig(), 94),
+    # a short generator on a long spectrogram: the large position tiles of every channel width (128, 64, 32 channels),
+    # the last tile of each stage partly past the end
+    (ho.HifiganConfig(initial_channel=128, upsample_rates=(2, 2), upsample_kernels=(4, 4)), 701),
+    # 256 -> 128 channels at 96 mel bins: input channels that are no multiple of 64 (one workgroup per CU shapes)
+    (ho.HifiganConfig(n_mels=96, initial_channel=256, upsample_rates=(4, 4), upsample_kernels=(8, 8), resblock_kernels=(3, 11),
+                      resblock_dilations=((1, 3, 5), (1, 3, 5))), 150),
+])
+def test_generator_long_inputs_match_oracle(pkg, cfg, t_mel):
+    gen, sd = build(cfg, seed=11)
+    mel = torch.randn(1, cfg.n_mels, t_mel, generator=torch.Generator().manual_seed(t_mel))
+    err = check(gen, sd, cfg, mel)
+    print(f"channels {cfg.initial_channel}, {t_mel} frames: max waveform error {err:.3e}")
+
+
 def test_generator_fixture(pkg):
     import os
     g = np.load(os.path.join(os.path.dirname(__file__), "golden", "vocoder_tiny.npz"))

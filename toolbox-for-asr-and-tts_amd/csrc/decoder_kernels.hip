@@ -197,10 +197,10 @@ __global__ __launch_bounds__(256) void ln_hidden_kernel(const uint16_t* __restri
 
 // ---- decoder: x += mask (conv11(mask LN2(t)) + mask LN2(t)) -----------------------------------------------------
 // t is the feed-forward output, LN2 the layer's norm2 (scale and shift applied here: a depth-wise convolution with
-// zero padding does not commute with a shift).  One workgroup = 32 token rows of one utterance: its four waves
-// normalise the 42 rows the window touches into LDS (rows outside the utterance's tokens are zero), then a thread
-// owns two channels and slides the 11 taps down the 32 rows.
-constexpr int kDecFsmnRows = 32;
+// zero padding does not commute with a shift).  One workgroup = 16 token rows of one utterance (52 KiB of LDS: three
+// workgroups per CU): its four waves normalise the 26 rows the window touches into LDS (rows outside the utterance's
+// tokens are zero), then a thread owns two channels and slides the 11 taps down the 16 rows.
+constexpr int kDecFsmnRows = 16;
 __global__ __launch_bounds__(256) void dec_fsmn_kernel(const DecFsmnParams p) {
     __shared__ __attribute__((aligned(16))) float tn[(kDecFsmnRows + 10) * 512];
     const int b = blockIdx.y;
@@ -211,12 +211,26 @@ __global__ __launch_bounds__(256) void dec_fsmn_kernel(const DecFsmnParams p) {
     const float4* g4 = reinterpret_cast<const float4*>(p.gamma + lane * 8);
     const float4* b4 = reinterpret_cast<const float4*>(p.beta + lane * 8);
     const float4 ga = g4[0], gb = g4[1], ba = b4[0], bb = b4[1];
-    for (int rr = wave; rr < kDecFsmnRows + 10; rr += 4) {
-        const int r = r0 + rr - 5;
+    // a wave's rows are all requested before the first one is reduced (one memory round trip, not one per row)
+    constexpr int kRowsPerWave = (kDecFsmnRows + 10 + 3) / 4;
+    float4 va[kRowsPerWave], vc[kRowsPerWave];
+#pragma unroll
+    for (int k = 0; k < kRowsPerWave; ++k) {
+        const int rr = wave + 4 * k, r = r0 + rr - 5;
+        va[k] = vc[k] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        if (rr < kDecFsmnRows + 10 && r >= 0 && r < ntok) {
+            const float4* src = reinterpret_cast<const float4*>(p.t + (static_cast<int64_t>(b) * p.N + r) * 512 + lane * 8);
+            va[k] = src[0];
+            vc[k] = src[1];
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < kRowsPerWave; ++k) {
+        const int rr = wave + 4 * k, r = r0 + rr - 5;
+        if (rr >= kDecFsmnRows + 10) break;
         float4 oa = make_float4(0.0f, 0.0f, 0.0f, 0.0f), ob = oa;
         if (r >= 0 && r < ntok) {
-            const float4* src = reinterpret_cast<const float4*>(p.t + (static_cast<int64_t>(b) * p.N + r) * 512 + lane * 8);
-            const float4 a = src[0], c = src[1];
+            const float4 a = va[k], c = vc[k];
             const float mean = wave_sum(a.x + a.y + a.z + a.w + c.x + c.y + c.z + c.w) * (1.0f / 512.0f);
             const float dx[8] = {a.x - mean, a.y - mean, a.z - mean, a.w - mean, c.x - mean, c.y - mean, c.z - mean, c.w - mean};
             float sq = 0.0f;
@@ -235,10 +249,17 @@ __global__ __launch_bounds__(256) void dec_fsmn_kernel(const DecFsmnParams p) {
 #pragma unroll
     for (int j = 0; j < 11; ++j) w[j] = reinterpret_cast<const float2*>(p.taps + j * 512)[tid];
     const float2* col = reinterpret_cast<const float2*>(tn) + tid;
+    float2 xin[kDecFsmnRows];
+#pragma unroll
     for (int i = 0; i < kDecFsmnRows; ++i) {
         const int r = r0 + i;
-        if (r >= p.N) break;
-        if (r >= ntok) continue;  // rows past the tokens keep their (finite) residual: nothing reads them as tokens
+        xin[i] = make_float2(0.0f, 0.0f);
+        if (r < ntok) xin[i] = reinterpret_cast<const float2*>(p.x + (static_cast<int64_t>(b) * p.N + r) * 512)[tid];
+    }
+#pragma unroll
+    for (int i = 0; i < kDecFsmnRows; ++i) {
+        const int r = r0 + i;
+        if (r >= ntok) break;  // rows past the tokens keep their (finite) residual: nothing reads them as tokens
         float2 acc = col[(i + 5) * 256];
 #pragma unroll
         for (int j = 0; j < 11; ++j) {
@@ -246,9 +267,7 @@ __global__ __launch_bounds__(256) void dec_fsmn_kernel(const DecFsmnParams p) {
             acc.x = fmaf(w[j].x, v.x, acc.x);
             acc.y = fmaf(w[j].y, v.y, acc.y);
         }
-        float2* xo = reinterpret_cast<float2*>(p.x + (static_cast<int64_t>(b) * p.N + r) * 512) + tid;
-        const float2 xv = *xo;
-        *xo = make_float2(xv.x + acc.x, xv.y + acc.y);
+        reinterpret_cast<float2*>(p.x + (static_cast<int64_t>(b) * p.N + r) * 512)[tid] = make_float2(xin[i].x + acc.x, xin[i].y + acc.y);
     }
 }
 
