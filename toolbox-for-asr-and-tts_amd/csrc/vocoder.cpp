@@ -144,7 +144,8 @@ namespace {
 struct VocBuffers {
     uint16_t* mel16;  // [B][T][n_mels]
     uint16_t* a[4];   // 16-bit activations: stage input, convolution scratch, ping, pong
-    float* r[4];      // f32: stage residual stream, ping, pong, sum over the residual blocks
+    float* r[3];      // f32: stage residual stream, ping, pong
+    float* out[4];    // f32: the output of each of a stage's residual blocks
     int64_t bytes;
 };
 VocBuffers voc_carve(const asrfe_ctx* ctx, void* ws, int B, int T) {
@@ -165,7 +166,8 @@ VocBuffers voc_carve(const asrfe_ctx* ctx, void* ws, int B, int T) {
     VocBuffers b;
     b.mel16 = reinterpret_cast<uint16_t*>(take(static_cast<int64_t>(B) * T * W.cfg.n_mels * 2));
     for (int i = 0; i < 4; ++i) b.a[i] = reinterpret_cast<uint16_t*>(take(worst * 2));
-    for (int i = 0; i < 4; ++i) b.r[i] = reinterpret_cast<float*>(take(worst * 4));
+    for (int i = 0; i < 3; ++i) b.r[i] = reinterpret_cast<float*>(take(worst * 4));
+    for (int i = 0; i < 4; ++i) b.out[i] = i < W.cfg.n_resblocks ? reinterpret_cast<float*>(take(worst * 4)) : nullptr;
     b.bytes = off;
     return b;
 }
@@ -195,17 +197,17 @@ extern "C" int32_t asrfe_vocoder_forward(asrfe_ctx* ctx, const float* mel, int32
     int32_t rc;
     if ((rc = launch_mel_to_ntc(ctx, mel, batch, W.cfg.n_mels, t_mel, b.mel16, s))) return rc;
 
-    auto conv = [&](const VocConv& cv, const uint16_t* x, int T, float act_slope, uint16_t* y16, const float* res_in, float* res_out,
-                    float* sum_out, int sum_mode) -> int32_t {
+    auto conv = [&](const VocConv& cv, const uint16_t* x, int T, float act_slope, uint16_t* y16, const float* res_in,
+                    float* res_out) -> int32_t {
         ConvParams p{};
         p.x = x; p.w = cv.w; p.bias = cv.bias; p.B = batch; p.Tin = T; p.Ci = cv.Ci; p.Co = cv.Co; p.taps = cv.k;
         p.off0 = -((cv.k - 1) / 2) * cv.dil; p.dtap = cv.dil; p.phases = 1; p.q_count = T;
         p.out_mul = 1; p.out_add0 = 0; p.out_add_step = 0; p.Tout = T;
-        p.slope = act_slope; p.y16 = y16; p.res_in = res_in; p.res_out = res_out; p.sum_out = sum_out; p.sum_mode = sum_mode;
+        p.slope = act_slope; p.y16 = y16; p.res_in = res_in; p.res_out = res_out;
         return launch_conv_mfma(ctx, p, s);
     };
     // conv_pre: only its activated output is needed (the first thing a stage does is lrelu)
-    if ((rc = conv(W.pre, b.mel16, t_mel, slope, b.a[0], nullptr, nullptr, nullptr, 0))) return rc;
+    if ((rc = conv(W.pre, b.mel16, t_mel, slope, b.a[0], nullptr, nullptr))) return rc;
     int T = t_mel;
     const int nrb = W.cfg.n_resblocks;
     for (size_t i = 0; i < W.stages.size(); ++i) {
@@ -224,11 +226,11 @@ extern "C" int32_t asrfe_vocoder_forward(asrfe_ctx* ctx, const float* mel, int32
             const float* xr = b.r[0];
             const uint16_t* xa = b.a[1];
             for (int q = 0; q < 3; ++q) {
-                if ((rc = conv(S.c1[j * 3 + q], xa, T, slope, b.a[0], nullptr, nullptr, nullptr, 0))) return rc;
-                const bool last = q == 2;
-                float* ro = last ? nullptr : b.r[1 + (q & 1)];
+                if ((rc = conv(S.c1[j * 3 + q], xa, T, slope, b.a[0], nullptr, nullptr))) return rc;
+                const bool last = q == 2;  // the block's output goes to its own buffer; nothing reads its activated copy
+                float* ro = last ? b.out[j] : b.r[1 + (q & 1)];
                 uint16_t* ao = last ? nullptr : b.a[2 + (q & 1)];
-                if ((rc = conv(S.c2[j * 3 + q], b.a[0], T, slope, ao, xr, ro, last ? b.r[3] : nullptr, last ? (j == 0 ? 1 : 2) : 0))) return rc;
+                if ((rc = conv(S.c2[j * 3 + q], b.a[0], T, slope, ao, xr, ro))) return rc;
                 xr = ro;
                 xa = ao;
             }
@@ -236,7 +238,7 @@ extern "C" int32_t asrfe_vocoder_forward(asrfe_ctx* ctx, const float* mel, int32
         // mean over the residual blocks, then the leaky ReLU in front of the next transposed convolution (or, with its
         // own slope, in front of the output convolution)
         const bool final_stage = i + 1 == W.stages.size();
-        if ((rc = launch_scale_act(ctx, b.r[3], 1.0f / static_cast<float>(nrb), final_stage ? W.cfg.final_slope : slope,
+        if ((rc = launch_scale_act(ctx, b.out, nrb, 1.0f / static_cast<float>(nrb), final_stage ? W.cfg.final_slope : slope,
                                    static_cast<int64_t>(batch) * T * S.Co, b.a[0], s)))
             return rc;
     }

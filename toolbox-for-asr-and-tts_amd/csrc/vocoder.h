@@ -24,8 +24,6 @@ struct ConvParams {
     uint16_t* y16;         // optional [B][Tout][Co]: lrelu(result)
     const float* res_in;   // optional [B][Tout][Co] f32 added to the result
     float* res_out;        // optional [B][Tout][Co] f32: the result
-    float* sum_out;        // optional [B][Tout][Co] f32: sum_mode 1 stores the result, 2 adds it
-    int sum_mode;
     int ci_tile;           // input channels staged per pass (filled by launch_conv_mfma)
     int flags;             // timing experiments (ASRFE_VOC_ABLATE): 1 no stores, 2 no k-steps, 4 no activation staging, 8 no residual load
 };
@@ -51,8 +49,9 @@ int32_t launch_conv_mfma(asrfe_ctx* ctx, const ConvParams& p, hipStream_t s);
 int32_t prepare_conv(asrfe_ctx* ctx);  // per-device kernel attributes; called by asrfe_load_vocoder_weights
 // mel f32 [B][n_mels][T] -> 16-bit [B][T][n_mels]
 int32_t launch_mel_to_ntc(asrfe_ctx* ctx, const float* mel, int B, int n_mels, int T, uint16_t* out, hipStream_t s);
-// y16 = lrelu(sum * scale, slope), n elements
-int32_t launch_scale_act(asrfe_ctx* ctx, const float* sum, float scale, float slope, int64_t n, uint16_t* y16, hipStream_t s);
+// y16 = lrelu((a + b + ...) * scale, slope) over n_in arrays (at most 4) of n elements
+int32_t launch_scale_act(asrfe_ctx* ctx, const float* const* in, int n_in, float scale, float slope, int64_t n, uint16_t* y16,
+                         hipStream_t s);
 // wav[b][t] = tanh(bias + sum over (tap < 7, ci) w[tap][ci] x[b][t + tap - 3][ci])
 int32_t launch_conv_post(asrfe_ctx* ctx, const uint16_t* x, const float* w, const float* bias, int B, int T, int C,
                          float* wav, hipStream_t s);

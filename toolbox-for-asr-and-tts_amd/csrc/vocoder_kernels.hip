@@ -27,10 +27,10 @@ __device__ __forceinline__ float lrelu(float v, float slope) { return v > 0.0f ?
 //   tile; 16-byte chunks swizzled by row so that a fragment read covers all banks) by LDS-DMA loads, three groups
 //   ahead; one counted wait + barrier per group.  Every workgroup of a launch reads the same weight rows: fetched once
 //   per workgroup and far ahead, they arrive from L2 without the latency of a hot line showing up in the loop.
-//   Accumulators start from bias + residual (loaded while the activations are staged), so the epilogue only stores.
+//   Accumulators start from the residual (loaded while the activations are staged): the epilogue adds the bias and stores.
 //   Per k-step (16 input channels of one tap) a wave issues NC * NP MFMAs on NC weight and NP activation fragments.
-// MFMA operand layout: lane (l31, h) holds 8 consecutive k = 8 consecutive input channels of one tap, of weight row l31
-// (A) and of position l31 (B); accumulator register 4 g + e is output channel 8 g + 4 h + e of position l31.
+// MFMA operand layout: lane (l31, h) holds 8 consecutive k = 8 consecutive input channels of one tap, of position l31
+// (A) and of weight row l31 (B); accumulator register 4 g + e is position 8 g + 4 h + e of output channel l31.
 constexpr int kConvRingSlots = 4;
 template <int NC>
 constexpr int conv_group_steps() { return NC == 4 ? 2 : 4; }  // a ring slot is NC * 32 rows x 32 GS bytes: 8 KiB at most
@@ -48,7 +48,7 @@ __global__ __launch_bounds__(256, OCC) void conv_tile_kernel(const ConvParams p)
     constexpr int kRowsPerInstr = 64 / kCpr;        // rows one LDS-DMA instruction (1 KiB) covers
     constexpr int kInstrPerWave = NC * 32 / kRowsPerInstr / 4;
     constexpr int kSwzShift = GS == 4 ? 1 : 2;      // rows sharing a 256-byte bank line: 2 (128-byte rows) or 4
-    constexpr int NSTG = (OCC == 1 && NP <= 3) ? 16 : 8;        // 16-byte activation chunks a thread keeps in flight while staging
+    constexpr int NSTG = OCC == 1 ? 16 : 8;        // 16-byte activation chunks a thread keeps in flight while staging
     static_assert(kInstrPerWave >= 1, "ring geometry");
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -67,32 +67,48 @@ __global__ __launch_bounds__(256, OCC) void conv_tile_kernel(const ConvParams p)
     const int zero_at = R * stride;
     const int ring_at = (zero_at + 16 + 127) & ~127;
     const uint32_t ring_lds = __builtin_amdgcn_readfirstlane(lds_addr_of(xs) + ring_at);
-    // the sum over a stage's residual blocks can ride in the accumulator too when nothing else is stored
-    const bool fold_sum = p.sum_mode == 2 && !p.res_out && !p.y16;
 
-    // ---- accumulators = bias (+ residual) (+ running sum): requested first, needed at the first MFMA
+#ifdef ASRFE_VOC_TIMING
+    // timing build: wave 0 of one workgroup in the middle of the grid prints cycle stamps of its phases
+    const bool tracing = (p.flags & 32) && blockIdx.x == gridDim.x / 2 && blockIdx.y == 0 && blockIdx.z == gridDim.z / 2 && wave == 0;
+    long long stamps[12];
+    int n_st = 0;
+#define VOC_STAMP() do { if (tracing) stamps[n_st] = __builtin_readcyclecounter(); ++n_st; } while (0)
+#else
+#define VOC_STAMP() do {} while (0)
+#endif
+    VOC_STAMP();  // 0: start
+    // ---- accumulators = bias (+ residual) (+ running sum): requested first, needed at the first MFMA.  The activation
+    // fragment is the MFMA's A operand and the weight fragment its B operand, so a lane owns ONE output channel
+    // (co0 + nc * 32 + l31) and register 4 g + e of a tile is position 8 g + 4 h + e: 32 lanes read or write the 32
+    // consecutive channels of a position, whole 128-byte lines of the f32 arrays.
+    // Output rows are addressed through buffer descriptors that end behind the item's last valid row (for this phase):
+    // an access to a row before the first or past the last is dropped (a load gives 0) by the hardware's range check,
+    // which looks at the per-lane offset; that offset is row * row bytes + channel bytes, one add per access.
     f32x16 acc[NC][NP];
-#pragma unroll
-    for (int np = 0; np < NP; ++np) {
-        const int q = q0 + wave * (NP * 32) + np * 32 + l31;
-        const int to = q * p.out_mul + p.out_add0 + ph * p.out_add_step;
-        const bool ok = q < p.q_count && to >= 0 && to < p.Tout;
-        const int64_t orow = (static_cast<int64_t>(b) * p.Tout + (ok ? to : 0)) * p.Co + co0 + 4 * h;
+    const int n_rows = max(0, min(p.Tout, p.q_count * p.out_mul + p.out_add0 + ph * p.out_add_step));
+    const int64_t item = static_cast<int64_t>(b) * p.Tout * p.Co;
+    const uint32_t row4 = static_cast<uint32_t>(p.Co) * 4u;  // bytes per f32 output row
+    // byte offset (f32 arrays) of register 0 of position tile 0 of this lane: row (first position + 4 h) * out_mul + ...
+    const uint32_t lane_off4 = static_cast<uint32_t>((q0 + wave * (NP * 32) + 4 * h) * p.out_mul + p.out_add0 + ph * p.out_add_step) * row4 +
+                               static_cast<uint32_t>(co0 + l31) * 4u;
+    const uint32_t step4 = static_cast<uint32_t>(p.out_mul) * row4;  // one position further
+    auto off4 = [&](int nc, int np, int r) { return lane_off4 + static_cast<uint32_t>(np * 32 + 8 * (r >> 2) + (r & 3)) * step4 + nc * 128; };
+    auto rsrc_of = [&](const void* ptr, int elem_bytes) {
+        return __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(static_cast<const char*>(ptr)) + item * elem_bytes, 0,
+                                                 n_rows * p.Co * elem_bytes, 0x00020000);
+    };
+    {   // accumulators start from the residual (the bias is added when they are stored: nothing here depends on a
+        // load, so all of them are in flight together and are waited for at the first MFMA)
+        const __amdgpu_buffer_rsrc_t res_rsrc = rsrc_of(p.res_in ? static_cast<const void*>(p.res_in) : p.bias, 4);
+        const bool with_res = p.res_in && !(p.flags & 8);
 #pragma unroll
         for (int nc = 0; nc < NC; ++nc)
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                float4 v = *reinterpret_cast<const float4*>(p.bias + co0 + nc * 32 + 8 * g + 4 * h);
-                if (p.res_in && ok && !(p.flags & 8)) {
-                    const float4 t = *reinterpret_cast<const float4*>(p.res_in + orow + nc * 32 + 8 * g);
-                    v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
-                }
-                if (fold_sum && ok) {
-                    const float4 t = *reinterpret_cast<const float4*>(p.sum_out + orow + nc * 32 + 8 * g);
-                    v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
-                }
-                acc[nc][np][4 * g] = v.x; acc[nc][np][4 * g + 1] = v.y; acc[nc][np][4 * g + 2] = v.z; acc[nc][np][4 * g + 3] = v.w;
-            }
+            for (int np = 0; np < NP; ++np)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    acc[nc][np][r] = with_res ? __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(res_rsrc, off4(nc, np, r), 0, 0)) : 0.0f;
     }
 
     // weight staging: instruction w + 4 i of a group (i < kInstrPerWave) moves ring rows kRowsPerInstr (w + 4 i) ...;
@@ -143,7 +159,9 @@ __global__ __launch_bounds__(256, OCC) void conv_tile_kernel(const ConvParams p)
                 if (dst[u] >= 0) *reinterpret_cast<uint4*>(xs + dst[u]) = v[u];
         }
         if (tid == 0) *reinterpret_cast<uint4*>(xs + zero_at) = make_uint4(0, 0, 0, 0);
+        VOC_STAMP();  // 1 (+ 3 per pass): staging issued and written
         __syncthreads();
+        VOC_STAMP();  // 2: staged everywhere
 
         // ---- k-steps s = tap * nblk + cb in groups of GS; a step past the last one multiplies by the zero chunk
         const int xbase = (wave * (NP * 32) + l31 + p.off0 - lo) * stride + h * 16;
@@ -178,38 +196,42 @@ __global__ __launch_bounds__(256, OCC) void conv_tile_kernel(const ConvParams p)
 #pragma unroll
                 for (int nc = 0; nc < NC; ++nc)
 #pragma unroll
-                    for (int np = 0; np < NP; ++np) acc[nc][np] = mfma32<F16>(wf[j & 1][nc], xf[j & 1][np], acc[nc][np]);
+                    for (int np = 0; np < NP; ++np) acc[nc][np] = mfma32<F16>(xf[j & 1][np], wf[j & 1][nc], acc[nc][np]);
             }
             slot = slot + 1 == NSLOT ? 0 : slot + 1;
         }
+        VOC_STAMP();  // 3: k-steps issued
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the ring's last (unused) groups
 
-    // ---- epilogue: stores (a lane owns one position and, per accumulator tile, 4 x 4 channels)
+    // ---- epilogue: bias, stores (32 lanes = the 32 consecutive channels of one position)
+    if (!((p.flags & 1) && acc[0][0][0] != 12345.0f)) {
+        const __amdgpu_buffer_rsrc_t ro_rsrc = rsrc_of(p.res_out ? static_cast<const void*>(p.res_out) : p.bias, 4);
+        const __amdgpu_buffer_rsrc_t y_rsrc = rsrc_of(p.y16 ? static_cast<const void*>(p.y16) : p.bias, 2);
+        float bv[NC];
 #pragma unroll
-    for (int np = 0; np < NP; ++np) {
-        const int q = q0 + wave * (NP * 32) + np * 32 + l31;
-        const int to = q * p.out_mul + p.out_add0 + ph * p.out_add_step;
-        if (q >= p.q_count || to < 0 || to >= p.Tout || ((p.flags & 1) && acc[0][np][0] != 12345.0f)) continue;
-        const int64_t orow = (static_cast<int64_t>(b) * p.Tout + to) * p.Co + co0 + 4 * h;
+        for (int nc = 0; nc < NC; ++nc) bv[nc] = p.bias[co0 + nc * 32 + l31];
 #pragma unroll
-        for (int nc = 0; nc < NC; ++nc)
+        for (int np = 0; np < NP; ++np)
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int64_t o = orow + nc * 32 + 8 * g;
-                const float v0 = acc[nc][np][4 * g], v1 = acc[nc][np][4 * g + 1], v2 = acc[nc][np][4 * g + 2], v3 = acc[nc][np][4 * g + 3];
-                if (p.res_out) *reinterpret_cast<float4*>(p.res_out + o) = make_float4(v0, v1, v2, v3);
-                if (p.sum_mode == 1 || fold_sum) {
-                    *reinterpret_cast<float4*>(p.sum_out + o) = make_float4(v0, v1, v2, v3);
-                } else if (p.sum_mode == 2) {
-                    const float4 t = *reinterpret_cast<const float4*>(p.sum_out + o);
-                    *reinterpret_cast<float4*>(p.sum_out + o) = make_float4(t.x + v0, t.y + v1, t.z + v2, t.w + v3);
+            for (int r = 0; r < 16; ++r)
+#pragma unroll
+                for (int nc = 0; nc < NC; ++nc) {
+                    const uint32_t o = off4(nc, np, r);
+                    const float v = acc[nc][np][r] + bv[nc];
+                    if (p.res_out) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, v), ro_rsrc, o, 0, 0);
+                    if (p.y16) __builtin_amdgcn_raw_buffer_store_b16(to_elem<F16>(lrelu(v, p.slope)), y_rsrc, o >> 1, 0, 0);
                 }
-                if (p.y16)
-                    *reinterpret_cast<uint2*>(p.y16 + o) = make_uint2(pack_elem2<F16>(lrelu(v0, p.slope), lrelu(v1, p.slope)),
-                                                                      pack_elem2<F16>(lrelu(v2, p.slope), lrelu(v3, p.slope)));
-            }
     }
+#ifdef ASRFE_VOC_TIMING
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    VOC_STAMP();
+    if (tracing && lane == 0) {
+        printf("conv Ci %d Co %d taps %d T %d NC %d NP %d OCC %d:", p.Ci, p.Co, p.taps, p.q_count, NC, NP, OCC);
+        for (int i = 1; i < n_st && i < 12; ++i) printf(" %lld", stamps[i] - stamps[i - 1]);
+        printf("\n");
+    }
+#endif
 }
 
 template <bool F16>
@@ -222,13 +244,18 @@ __global__ __launch_bounds__(256) void mel_to_ntc_kernel(const float* __restrict
     out[static_cast<int64_t>(b) * T * n_mels + i] = to_elem<F16>(mel[(static_cast<int64_t>(b) * n_mels + c) * T + t]);
 }
 
+struct ScaleActIn { const float* in[4]; };
 template <bool F16>
-__global__ __launch_bounds__(256) void scale_act_kernel(const float* __restrict__ sum, float scale, float slope, int64_t n4,
+__global__ __launch_bounds__(256) void scale_act_kernel(const ScaleActIn src, int n_in, float scale, float slope, int64_t n4,
                                                         uint16_t* __restrict__ y16) {
     saturate_fp16_conversions<F16>();
     const int64_t i = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
     if (i >= n4) return;
-    const float4 v = reinterpret_cast<const float4*>(sum)[i];
+    float4 v = reinterpret_cast<const float4*>(src.in[0])[i];
+    for (int k = 1; k < n_in; ++k) {
+        const float4 t = reinterpret_cast<const float4*>(src.in[k])[i];
+        v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
+    }
     reinterpret_cast<uint2*>(y16)[i] = make_uint2(pack_elem2<F16>(lrelu(v.x * scale, slope), lrelu(v.y * scale, slope)),
                                                   pack_elem2<F16>(lrelu(v.z * scale, slope), lrelu(v.w * scale, slope)));
 }
@@ -275,12 +302,12 @@ int64_t conv_lds_bytes(int rows, int stride, int nc) {
 constexpr int kMaxShapes = 5;
 const ConvShape kShapes[3][kMaxShapes] = {{{8, 2}, {4, 2}, {2, 2}, {1, 2}, {0, 0}},   // NC = 1
                                           {{4, 2}, {2, 2}, {1, 2}, {0, 0}, {0, 0}},   // NC = 2
-                                          {{2, 2}, {4, 1}, {3, 1}, {2, 1}, {1, 1}}};  // NC = 4
+                                          {{2, 2}, {3, 1}, {2, 1}, {1, 1}, {0, 0}}};  // NC = 4
 
 template <bool F16>
 const void* conv_fn(int nc, int np, int occ) {
 #define CF(NCV, NPV, OCCV) if (nc == NCV && np == NPV && occ == OCCV) return reinterpret_cast<const void*>(conv_tile_kernel<F16, NCV, NPV, OCCV>)
-    CF(4, 2, 2); CF(4, 1, 1); CF(4, 2, 1); CF(4, 3, 1); CF(4, 4, 1);
+    CF(4, 2, 2); CF(4, 1, 1); CF(4, 2, 1); CF(4, 3, 1);
     CF(2, 1, 2); CF(2, 2, 2); CF(2, 4, 2);
     CF(1, 1, 2); CF(1, 2, 2); CF(1, 4, 2); CF(1, 8, 2);
 #undef CF
@@ -316,8 +343,11 @@ int32_t launch_conv_mfma(asrfe_ctx* ctx, const ConvParams& pin, hipStream_t s) {
         return set_err(ctx, ASRFE_ERR_SHAPE, "vocoder convolution: input channels must be a multiple of 16, output channels of 32");
     if (static_cast<int64_t>(p.B) * p.phases > 65535) return set_err(ctx, ASRFE_ERR_SHAPE, "vocoder convolution: batch * stride too large");
     if (p.taps * p.Ci < 8) return set_err(ctx, ASRFE_ERR_SHAPE, "vocoder convolution: too few weights");
+    // (output rows are addressed by 32-bit byte offsets inside an item, up to eight position tiles past its end)
+    if ((static_cast<int64_t>(p.Tout) + 8192ll * p.out_mul) * p.Co * 4 >= (int64_t{1} << 31))
+        return set_err(ctx, ASRFE_ERR_SHAPE, "vocoder convolution: one item's output must stay below 2 GiB");
     static const int ablate = [] { const char* e = getenv("ASRFE_VOC_ABLATE"); return e ? atoi(e) : 0; }();
-    p.flags = ablate & 15;
+    p.flags = ablate & (15 | 32);
     const int nci = p.Co % 128 == 0 ? 2 : (p.Co % 64 == 0 ? 1 : 0), nc = 1 << nci;
     const int span = (p.taps - 1) * (p.dtap < 0 ? -p.dtap : p.dtap);
     // positions per workgroup: the first shape of the list that fits in its share of the LDS and wastes under a tenth
@@ -357,12 +387,16 @@ int32_t launch_mel_to_ntc(asrfe_ctx* ctx, const float* mel, int B, int n_mels, i
     return ASRFE_OK;
 }
 
-int32_t launch_scale_act(asrfe_ctx* ctx, const float* sum, float scale, float slope, int64_t n, uint16_t* y16, hipStream_t s) {
+int32_t launch_scale_act(asrfe_ctx* ctx, const float* const* in, int n_in, float scale, float slope, int64_t n, uint16_t* y16,
+                         hipStream_t s) {
     if (n <= 0) return ASRFE_OK;
+    if (n_in < 1 || n_in > 4) return set_err(ctx, ASRFE_ERR_BAD_ARG, "stage average: 1..4 inputs");
+    ScaleActIn src{};
+    for (int k = 0; k < n_in; ++k) src.in[k] = in[k];
     const int64_t n4 = n / 4;  // (channel counts are multiples of 32)
     const dim3 grid(static_cast<unsigned>((n4 + 255) / 256)), block(256);
-    if (ctx->cfg.enc_compute_dtype == ASRFE_DT_F16) hipLaunchKernelGGL(scale_act_kernel<true>, grid, block, 0, s, sum, scale, slope, n4, y16);
-    else hipLaunchKernelGGL(scale_act_kernel<false>, grid, block, 0, s, sum, scale, slope, n4, y16);
+    if (ctx->cfg.enc_compute_dtype == ASRFE_DT_F16) hipLaunchKernelGGL(scale_act_kernel<true>, grid, block, 0, s, src, n_in, scale, slope, n4, y16);
+    else hipLaunchKernelGGL(scale_act_kernel<false>, grid, block, 0, s, src, n_in, scale, slope, n4, y16);
     VOC_CHECK_LAUNCH("stage average");
     return ASRFE_OK;
 }
