@@ -452,9 +452,18 @@ def main():
         with torch.cuda.graph(g1):
             eng_1.run(pcm_1, lens_1)
         t_graph = timed(g1.replay, 20)
-        result["single_clip_3s"] = {"eager_ms": 1e3 * t_eager, "graph_ms": 1e3 * t_graph,
-                                    "note": "one 3 s utterance per step (T' = 50 rows): latency, not throughput"}
-        del eng_1, g1
+        head_1 = ParaformerHead(eng_1.ctx)
+        head_1.load_state_dict(decoder_state_dict(seed=1))
+
+        def clip_to_ids():
+            o, l = eng_1.run(pcm_1, lens_1)
+            head_1.forward(o, l)
+
+        t_ids = timed(clip_to_ids, 20)
+        result["single_clip_3s"] = {"eager_ms": 1e3 * t_eager, "graph_ms": 1e3 * t_graph, "to_token_ids_ms": 1e3 * t_ids,
+                                    "note": "one 3 s utterance per step (T' = 50 rows): latency, not throughput; "
+                                            "to_token_ids_ms adds the CIF predictor + 16-block decoder + arg-max"}
+        del eng_1, g1, head_1
 
     if rank == 0 and not args.no_stages:
         # ---- per-kernel HIP-event pass (same process, same inputs, after the timed region) ----------

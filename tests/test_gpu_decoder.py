@@ -25,9 +25,17 @@ def pkg():
     return p
 
 
-def make_head(pkg, cfg, sd):
+# launch plans of the matrix products: the library's default (calls of up to 2048 rows take the latency plan's product)
+# and the throughput kernel only
+PLANS = [None, 0]
+
+
+def make_head(pkg, cfg, sd, small_rows=None):
     from toolbox_for_asr_and_tts_amd.decoder import ParaformerHead
-    head = ParaformerHead(pkg.Context(), num_blocks=cfg.num_blocks, linear_units=cfg.linear_units, vocab_size=cfg.vocab_size)
+    lib_cfg = pkg.default_config()
+    if small_rows is not None:
+        lib_cfg.enc_small_batch_rows = small_rows
+    head = ParaformerHead(pkg.Context(lib_cfg), num_blocks=cfg.num_blocks, linear_units=cfg.linear_units, vocab_size=cfg.vocab_size)
     head.load_state_dict(sd)
     return head
 
@@ -61,11 +69,12 @@ def check_against_oracle(head, cfg, sd, mem, lens, n_max=None):
     return worst
 
 
-def test_decoder_tiny_fixture(pkg):
+@pytest.mark.parametrize("plan", PLANS)
+def test_decoder_tiny_fixture(pkg, plan):
     g = np.load(os.path.join(GOLDEN, "decoder_tiny.npz"))
     cfg = po.DecoderConfig(num_blocks=int(g["num_blocks"]), vocab_size=int(g["vocab_size"]))
     sd = po.make_state_dict(cfg, seed=int(g["seed"]))
-    head = make_head(pkg, cfg, sd)
+    head = make_head(pkg, cfg, sd, plan)
     mem = torch.from_numpy(g["memory"])
     r = head.forward(mem.cuda(), torch.from_numpy(g["lens"]), return_logits=True, return_alphas=True)
     torch.cuda.synchronize()
@@ -78,22 +87,24 @@ def test_decoder_tiny_fixture(pkg):
     assert r["logits"].shape[2] == 300 and head.logits_stride == 512
 
 
-def test_predictor_and_decoder_ragged_lengths(pkg):
+@pytest.mark.parametrize("plan", PLANS)
+def test_predictor_and_decoder_ragged_lengths(pkg, plan):
     """Lengths around the edges: an empty utterance (no tokens), a single frame, lengths that end a 64-key tile."""
     cfg = po.DecoderConfig(num_blocks=2, vocab_size=515)
     sd = po.make_state_dict(cfg, seed=11)
-    head = make_head(pkg, cfg, sd)
+    head = make_head(pkg, cfg, sd, plan)
     g = torch.Generator().manual_seed(12)
     mem = torch.randn(5, 130, 512, generator=g)
     lens = torch.tensor([130, 64, 1, 0, 65], dtype=torch.int32)
     check_against_oracle(head, cfg, sd, mem, lens)
 
 
-def test_full_size_decoder(pkg):
+@pytest.mark.parametrize("plan", PLANS)
+def test_full_size_decoder(pkg, plan):
     """The paraformer-large head: 16 blocks + closing block, linear_units 2048, vocabulary 8404; B = 2, T' = 100."""
     cfg = po.DecoderConfig()
     sd = po.make_state_dict(cfg, seed=13)
-    head = make_head(pkg, cfg, sd)
+    head = make_head(pkg, cfg, sd, plan)
     g = torch.Generator().manual_seed(14)
     mem = torch.randn(2, 100, 512, generator=g)
     lens = torch.tensor([100, 73], dtype=torch.int32)

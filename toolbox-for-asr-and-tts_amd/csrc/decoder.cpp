@@ -238,6 +238,10 @@ int32_t gemm(asrfe_ctx* ctx, const uint16_t* A, int lda, const uint16_t* Wt, int
     GemmParams g{};
     g.A = A; g.lda = lda; g.W = Wt; g.ldw = ldw; g.bias = bias; g.M = M; g.N = N; g.K = K; g.out = out; g.ldo = ldo;
     g.add32 = add32; g.ld32 = ldo;
+    // a handful of rows (one short utterance): the latency plan's product, which spreads the weights over the chip
+    // instead of giving one workgroup 256 rows
+    const int small = ctx->cfg.enc_small_batch_rows;
+    if (M <= small && K % 512 == 0 && K <= 3072 && N % 32 == 0) return launch_skinny_gemm(ctx, g, epi, s);
     return launch_gemm(ctx, g, epi, s);
 }
 }  // namespace

@@ -21,8 +21,12 @@ def main():
     ap.add_argument("--tp", type=int, default=500)
     ap.add_argument("--n-max", type=int, default=256)
     ap.add_argument("--iters", type=int, default=10)
+    ap.add_argument("--small-rows", type=int, default=None, help="enc_small_batch_rows of the context (0: throughput plan only)")
     args = ap.parse_args()
-    ctx = _lib.Context()
+    cfg = _lib.default_config()
+    if args.small_rows is not None:
+        cfg.enc_small_batch_rows = args.small_rows
+    ctx = _lib.Context(cfg)
     head = ParaformerHead(ctx)
     head.load_state_dict(decoder_state_dict(seed=1))
     g = torch.Generator(device="cpu").manual_seed(3)
