@@ -27,7 +27,8 @@ def main():
     out = {"source": "rocprofv3 --pmc, two SQ passes over tools/fbank_bench.py (tools/pmc_fbank.sh), fbank-only kernel, 256 x 30 s",
            "csrc_tag": csrc_tag(), "kernel_cycles": cyc,
            "lds_busy_frac": round(lds, 4), "lds_bank_conflict_frac": round(conflict, 4), "valu_busy_frac": round(valu, 4),
-           "insts_per_frame": {"valu": c["SQ_INSTS_VALU"] / (256 * 2998.0) * 16 / 64, "lds": c["SQ_INSTS_LDS"] / (256 * 2998.0) * 16 / 64},
+           # wave-level instructions per group of 4 frames (one wave carries 4 frames at a time)
+           "insts_per_4_frames": {"valu": round(c["SQ_INSTS_VALU"] / (256 * 2998.0 / 4), 1), "lds": round(c["SQ_INSTS_LDS"] / (256 * 2998.0 / 4), 1)},
            # the kernel cannot run faster than its busiest unit allows
            "speedup_bound_as_is": round(1.0 / max(lds, valu), 3),
            "speedup_bound_without_bank_conflicts": round(1.0 / max(lds - conflict, valu), 3)}
