@@ -25,7 +25,7 @@ struct ConvParams {
     const float* res_in;   // optional [B][Tout][Co] f32 added to the result
     float* res_out;        // optional [B][Tout][Co] f32: the result
     int ci_tile;           // input channels staged per pass (filled by launch_conv_mfma)
-    int flags;             // timing experiments (ASRFE_VOC_ABLATE): 1 no stores, 2 no k-steps, 4 no activation staging, 8 no residual load
+    int flags;             // timing experiments (ASRFE_VOC_ABLATE; read by a -DASRFE_VOC_TIMING build only, bit 16 by the launcher)
 };
 
 struct VocConv {

@@ -68,9 +68,16 @@ __global__ __launch_bounds__(256, OCC) void conv_tile_kernel(const ConvParams p)
     const int ring_at = (zero_at + 16 + 127) & ~127;
     const uint32_t ring_lds = __builtin_amdgcn_readfirstlane(lds_addr_of(xs) + ring_at);
 
+    // timing experiments (a build with -DASRFE_VOC_TIMING and ASRFE_VOC_ABLATE in the environment; results are wrong when
+    // a bit below 16 is set): 1 no stores, 2 no k-steps, 4 no activation staging, 8 no residual load, 32 phase stamps
 #ifdef ASRFE_VOC_TIMING
-    // timing build: wave 0 of one workgroup in the middle of the grid prints cycle stamps of its phases
-    const bool tracing = (p.flags & 32) && blockIdx.x == gridDim.x / 2 && blockIdx.y == 0 && blockIdx.z == gridDim.z / 2 && wave == 0;
+    const int tflags = p.flags;
+#else
+    constexpr int tflags = 0;
+#endif
+#ifdef ASRFE_VOC_TIMING
+    // wave 0 of one workgroup in the middle of the grid prints cycle stamps of its phases
+    const bool tracing = (tflags & 32) && blockIdx.x == gridDim.x / 2 && blockIdx.y == 0 && blockIdx.z == gridDim.z / 2 && wave == 0;
     long long stamps[12];
     int n_st = 0;
 #define VOC_STAMP() do { if (tracing) stamps[n_st] = __builtin_readcyclecounter(); ++n_st; } while (0)
@@ -78,7 +85,7 @@ __global__ __launch_bounds__(256, OCC) void conv_tile_kernel(const ConvParams p)
 #define VOC_STAMP() do {} while (0)
 #endif
     VOC_STAMP();  // 0: start
-    // ---- accumulators = bias (+ residual) (+ running sum): requested first, needed at the first MFMA.  The activation
+    // ---- accumulators start from the residual: requested first, needed at the first MFMA.  The activation
     // fragment is the MFMA's A operand and the weight fragment its B operand, so a lane owns ONE output channel
     // (co0 + nc * 32 + l31) and register 4 g + e of a tile is position 8 g + 4 h + e: 32 lanes read or write the 32
     // consecutive channels of a position, whole 128-byte lines of the f32 arrays.
@@ -101,7 +108,7 @@ __global__ __launch_bounds__(256, OCC) void conv_tile_kernel(const ConvParams p)
     {   // accumulators start from the residual (the bias is added when they are stored: nothing here depends on a
         // load, so all of them are in flight together and are waited for at the first MFMA)
         const __amdgpu_buffer_rsrc_t res_rsrc = rsrc_of(p.res_in ? static_cast<const void*>(p.res_in) : p.bias, 4);
-        const bool with_res = p.res_in && !(p.flags & 8);
+        const bool with_res = p.res_in && !(tflags & 8);
 #pragma unroll
         for (int nc = 0; nc < NC; ++nc)
 #pragma unroll
@@ -141,7 +148,7 @@ __global__ __launch_bounds__(256, OCC) void conv_tile_kernel(const ConvParams p)
 
         // ---- stage rows [q0 + lo, q0 + lo + R) x channels [ci0, ci0 + CiT)
         const int n_chunks = R * cpr;
-        for (int i0 = tid; i0 < ((p.flags & 4) ? 0 : n_chunks); i0 += NSTG * 256) {
+        for (int i0 = tid; i0 < ((tflags & 4) ? 0 : n_chunks); i0 += NSTG * 256) {
             uint4 v[NSTG];
             int dst[NSTG];
 #pragma unroll
@@ -182,7 +189,7 @@ __global__ __launch_bounds__(256, OCC) void conv_tile_kernel(const ConvParams p)
         u16x8 xf[2][NP], wf[2][NC];
         read_x(xf[0]);
         int slot = 0;
-        for (int g = 0; g < ((p.flags & 2) ? 0 : G); ++g) {
+        for (int g = 0; g < ((tflags & 2) ? 0 : G); ++g) {
             // this wave's part of group g has landed (the younger groups may still fly), then all waves meet: group g
             // is complete and nobody reads group g - 1 any more, whose slot takes group g + NSLOT - 1
             asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"((NSLOT - 2) * kInstrPerWave) : "memory");
@@ -205,7 +212,7 @@ __global__ __launch_bounds__(256, OCC) void conv_tile_kernel(const ConvParams p)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the ring's last (unused) groups
 
     // ---- epilogue: bias, stores (32 lanes = the 32 consecutive channels of one position)
-    if (!((p.flags & 1) && acc[0][0][0] != 12345.0f)) {
+    if (!((tflags & 1) && acc[0][0][0] != 12345.0f)) {
         const __amdgpu_buffer_rsrc_t ro_rsrc = rsrc_of(p.res_out ? static_cast<const void*>(p.res_out) : p.bias, 4);
         const __amdgpu_buffer_rsrc_t y_rsrc = rsrc_of(p.y16 ? static_cast<const void*>(p.y16) : p.bias, 2);
         float bv[NC];
