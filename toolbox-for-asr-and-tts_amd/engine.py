@@ -59,15 +59,22 @@ class AsrEngine:
 
     def __init__(self, batch: int, max_samples: int, cfg: _lib.Config | None = None, device=None,
                  out_dtype=torch.float32, cmvn: tuple | None = None, state_dict=None, n_streams: int = 1,
-                 n_buckets: int = 0, session_float: bool = False):
+                 n_buckets: int = 0, session_float: bool = False, ctx: _lib.Context | None = None):
         # session_float: float32 PCM is a streaming-session buffer in [-1, 1]; the frontend kernel then applies the
         # reference's int16 hand-off (clip, x 32767, truncate; voice_interface.py:1997-2010) while loading, so the
         # result equals that of the int16 WAV the reference writes.  Otherwise float32 PCM is scaled by 32768 as
         # FunASR's loader does.
         self.session_float = bool(session_float)
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
-        with torch.cuda.device(self.device):
-            self.ctx = _lib.Context(cfg)
+        # ctx: another engine's context on the same device (its configuration, CMVN table and encoder weights are then
+        # shared: pass neither cfg, cmvn nor state_dict); engines of different batch sizes can serve one model that way
+        if ctx is not None:
+            if cfg is not None or cmvn is not None or state_dict is not None:
+                raise ValueError("AsrEngine: a shared context brings its own configuration, CMVN table and weights")
+            self.ctx = ctx
+        else:
+            with torch.cuda.device(self.device):
+                self.ctx = _lib.Context(cfg)
         c = self.ctx.cfg
         self.frontend = WavFrontend(fs=c.sample_rate, n_mels=c.n_mels, lfr_m=c.lfr_m, lfr_n=c.lfr_n, ctx=self.ctx,
                                     cmvn=cmvn)

@@ -1,0 +1,200 @@
+"""Loading a local Paraformer model directory, as the reference does with ``funasr.AutoModel(model=<dir>, device="cuda:0",
+disable_update=True, disable_pbar=True)`` (/root/reference/voice-service/app/services/voice_interface.py:683-691), and
+the ``generate(input=...)`` call that returns ``[{"key": ..., "text": ...}]``.
+
+A model directory of the ModelScope / FunASR layout holds
+    config.yaml   frontend_conf / encoder_conf / predictor_conf / decoder_conf (and optionally ``token_list``)
+    am.mvn        CMVN statistics (Kaldi nnet text: <AddShift>, <Rescale>)
+    model.pt      the checkpoint: a ``state_dict`` (possibly under the key "state_dict" or "model")
+    tokens.json   the token list (or tokens.txt, one token per line)
+Nothing is executed from those files: YAML is read with the safe loader, the checkpoint with
+``torch.load(weights_only=True)``.  Everything runs on the device through libasrfe; there is no CPU path."""
+from __future__ import annotations
+
+import json
+import os
+import wave
+
+import numpy as np
+import torch
+import yaml
+
+from . import _lib
+from .decoder import ParaformerHead
+from .engine import AsrEngine
+from .frontend import load_cmvn
+
+
+def read_model_dir(path: str) -> dict:
+    """-> {"config": dict, "cmvn": (shift, scale), "tokens": list | None, "state_dict": dict}; raises FileNotFoundError /
+    ValueError with the offending file's name."""
+    if not os.path.isdir(path):
+        raise FileNotFoundError(f"{path}: not a model directory")
+    cfg_file = os.path.join(path, "config.yaml")
+    if not os.path.isfile(cfg_file):
+        raise FileNotFoundError(f"{cfg_file}: missing")
+    with open(cfg_file, "r", encoding="utf-8") as f:
+        config = yaml.safe_load(f) or {}
+    if not isinstance(config, dict):
+        raise ValueError(f"{cfg_file}: not a mapping")
+    cmvn_file = os.path.join(path, str((config.get("frontend_conf") or {}).get("cmvn_file") or "am.mvn"))
+    if not os.path.isfile(cmvn_file):
+        cmvn_file = os.path.join(path, "am.mvn")
+    cmvn = load_cmvn(cmvn_file)
+    tokens = None
+    for name in ("tokens.json", "tokens.txt"):
+        tf = os.path.join(path, name)
+        if os.path.isfile(tf):
+            with open(tf, "r", encoding="utf-8") as f:
+                tokens = json.load(f) if name.endswith(".json") else [ln.rstrip("\n").split(" ")[0] for ln in f if ln.strip()]
+            break
+    if tokens is None and isinstance(config.get("token_list"), list):
+        tokens = list(config["token_list"])
+    ckpt = None
+    for name in ("model.pt", "model.pb", "model.pth"):
+        cf = os.path.join(path, name)
+        if os.path.isfile(cf):
+            ckpt = torch.load(cf, map_location="cpu", weights_only=True)
+            break
+    if ckpt is None:
+        raise FileNotFoundError(f"{path}: no model.pt")
+    for key in ("state_dict", "model"):
+        if isinstance(ckpt, dict) and isinstance(ckpt.get(key), dict):
+            ckpt = ckpt[key]
+    if not isinstance(ckpt, dict) or not any(k.startswith("encoder.") for k in ckpt):
+        raise ValueError(f"{path}: the checkpoint holds no encoder.* tensors")
+    return {"config": config, "cmvn": cmvn, "tokens": tokens, "state_dict": ckpt}
+
+
+def library_config(config: dict, small_batch_rows: int | None = None) -> _lib.Config:
+    """The library configuration a FunASR ``config.yaml`` asks for (missing entries keep paraformer-large's values)."""
+    c = _lib.default_config()
+    fe = config.get("frontend_conf") or {}
+    en = config.get("encoder_conf") or {}
+    c.sample_rate = int(fe.get("fs", c.sample_rate))
+    c.n_mels = int(fe.get("n_mels", c.n_mels))
+    c.frame_length = int(round(float(fe.get("frame_length", 25)) * c.sample_rate / 1000.0))
+    c.frame_shift = int(round(float(fe.get("frame_shift", 10)) * c.sample_rate / 1000.0))
+    c.lfr_m = int(fe.get("lfr_m", c.lfr_m))
+    c.lfr_n = int(fe.get("lfr_n", c.lfr_n))
+    window = str(fe.get("window", "hamming"))
+    if window != "hamming":
+        raise ValueError(f"frontend_conf.window = {window!r}: only the Hamming window is built")
+    # (a dither entry is ignored: FunASR's own inference path runs the frontend with dither switched off as well)
+    c.enc_input_size = c.lfr_m * c.n_mels
+    c.enc_output_size = int(en.get("output_size", c.enc_output_size))
+    c.enc_heads = int(en.get("attention_heads", c.enc_heads))
+    c.enc_linear_units = int(en.get("linear_units", c.enc_linear_units))
+    c.enc_num_blocks = int(en.get("num_blocks", c.enc_num_blocks))
+    c.enc_kernel_size = int(en.get("kernel_size", c.enc_kernel_size))
+    c.enc_sanm_shift = int(en.get("sanm_shfit", en.get("sanm_shift", c.enc_sanm_shift)))
+    if small_batch_rows is not None:
+        c.enc_small_batch_rows = int(small_batch_rows)
+    return c
+
+
+def _read_wav(path: str) -> np.ndarray:
+    with wave.open(path, "rb") as wf:
+        if wf.getsampwidth() != 2:
+            raise ValueError(f"{path}: only 16-bit PCM WAV files are read here")
+        if wf.getframerate() != 16000:
+            raise ValueError(f"{path}: {wf.getframerate()} Hz; the model takes 16 kHz")
+        pcm = np.frombuffer(wf.readframes(wf.getnframes()), dtype=np.int16)
+        if wf.getnchannels() > 1:
+            pcm = pcm.reshape(-1, wf.getnchannels()).astype(np.int32).mean(axis=1).astype(np.int16)
+    return pcm
+
+
+class AutoModel:
+    """``AutoModel(model=<local directory>, device="cuda:0")`` for a Paraformer directory; ``generate(input=...)`` takes
+    what the reference passes (a WAV path, a float32 numpy array in [-1, 1] at 16 kHz, an int16 array, a torch tensor, or
+    a list of those) and returns one ``{"key", "text"}`` per utterance (``"token_ids"`` too; text needs the directory's
+    token list).  ``batch`` utterances of up to ``max_seconds`` go through the device at once; longer inputs are refused
+    (the reference's VAD cuts them into segments first: that model is not part of this package)."""
+
+    def __init__(self, model: str, device: str = "cuda:0", batch: int = 16, max_seconds: float = 30.0,
+                 disable_update: bool = True, disable_pbar: bool = True, small_batch_rows: int | None = None, **kwargs):
+        if not str(device).startswith("cuda"):
+            raise ValueError("AutoModel: this package runs on a GPU only (device='cuda:N')")
+        parts = read_model_dir(model)
+        self.model_path = model
+        self.device = torch.device(device)
+        self.kwargs = parts["config"]
+        cfg = library_config(parts["config"], small_batch_rows)
+        self.max_samples = int(max_seconds * cfg.sample_rate)
+        sd = parts["state_dict"]
+        self.engine = AsrEngine(batch=batch, max_samples=self.max_samples, cfg=cfg, device=self.device, cmvn=parts["cmvn"],
+                                state_dict=sd)
+        # one utterance at a time (the service's shape) goes through engines of batch 1 on the same context and weights,
+        # sized for 5 / 10 / 20 s and the full length and made on first use: a short call then computes its own frames
+        # only and takes the library's latency plan instead of a batch of padding
+        self._one = {}
+        de = parts["config"].get("decoder_conf") or {}
+        pr = parts["config"].get("predictor_conf") or {}
+        vocab = len(parts["tokens"]) if parts["tokens"] else int(sd["decoder.output_layer.weight"].shape[0])
+        self.head = ParaformerHead(self.engine.ctx, num_blocks=int(de.get("num_blocks", 16)),
+                                   linear_units=int(de.get("linear_units", 2048)), vocab_size=vocab,
+                                   kernel_size=int(de.get("kernel_size", 11)),
+                                   tail_threshold=float(pr.get("tail_threshold", 0.45)), threshold=float(pr.get("threshold", 1.0)),
+                                   smooth_factor=float(pr.get("smooth_factor", 1.0)),
+                                   noise_threshold=float(pr.get("noise_threshold", 0.0)), token_list=parts["tokens"])
+        self.head.load_state_dict(sd)
+        self.batch = batch
+
+    def _engine_for(self, n_clips: int, n_samples: int) -> AsrEngine:
+        if n_clips > 1:
+            return self.engine
+        sr = self.engine.ctx.cfg.sample_rate
+        for seconds in (5, 10, 20):
+            if n_samples <= seconds * sr < self.max_samples:
+                key = seconds * sr
+                break
+        else:
+            key = self.max_samples
+        if key not in self._one:
+            self._one[key] = AsrEngine(batch=1, max_samples=key, device=self.device, ctx=self.engine.ctx)
+        return self._one[key]
+
+    # ---- input handling ----------------------------------------------------------------------------------------------
+    @staticmethod
+    def _to_int16(x) -> np.ndarray:
+        if isinstance(x, str):
+            return _read_wav(x)
+        if isinstance(x, torch.Tensor):
+            x = x.detach().cpu().numpy()
+        a = np.asarray(x)
+        if a.ndim != 1:
+            a = a.reshape(-1)
+        if a.dtype == np.int16:
+            return a
+        # float PCM in [-1, 1): FunASR's loader scales by 32768 in the frontend; rounding to the int16 grid first is what
+        # a WAV file of the same signal would hold
+        return np.clip(np.rint(a.astype(np.float64) * 32768.0), -32768, 32767).astype(np.int16)
+
+    def generate(self, input, cache=None, is_final: bool = True, **kwargs) -> list:
+        items = list(input) if isinstance(input, (list, tuple)) else [input]
+        keys = [os.path.splitext(os.path.basename(x))[0] if isinstance(x, str) else f"rand_key_{i}" for i, x in enumerate(items)]
+        clips = [self._to_int16(x) for x in items]
+        for k, c in zip(keys, clips):
+            if c.shape[0] > self.max_samples:
+                raise ValueError(f"{k}: {c.shape[0]} samples exceed the engine's {self.max_samples}; cut the input into segments")
+        results = [None] * len(clips)
+        order = sorted(range(len(clips)), key=lambda i: clips[i].shape[0])  # length-sorted batches, as FunASR builds them
+        for lo in range(0, len(order), self.batch):
+            idx = order[lo:lo + self.batch]
+            n = max(clips[i].shape[0] for i in idx)
+            eng = self._engine_for(len(idx), n)
+            pcm = np.zeros((eng.batch, max(n, 1)), dtype=np.int16)
+            lens = np.zeros((eng.batch,), dtype=np.int32)
+            for row, i in enumerate(idx):
+                pcm[row, :clips[i].shape[0]] = clips[i]
+                lens[row] = clips[i].shape[0]
+            out, olens = eng.run(torch.from_numpy(pcm).to(self.device), torch.from_numpy(lens).to(self.device))
+            r = self.head.forward(out, olens)
+            rows = r["token_ids"].cpu().tolist()
+            for row, i in enumerate(idx):
+                ids = self.head.clean_ids(rows[row])
+                item = {"key": keys[i], "token_ids": ids}
+                item["text"] = self.head.ids2text(ids) if self.head.token_list is not None else ""
+                results[i] = item
+        return results
