@@ -166,11 +166,17 @@ def cpu_baseline(sd, n_clips: int, batch: int = 8):
     }
 
 
+def free_port() -> int:
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
 def launch_ranks(n: int) -> int:
     """``python bench.py --gpus N`` without a launcher: start N copies of this script, one rank per GPU, relay rank 0's
     output and return non-zero if any rank fails.  Runs BEFORE this process makes any GPU call (counting devices does
     not initialise the GPU) and starts fresh child processes: a process that has touched the GPU is never replaced."""
-    import socket
     import subprocess
 
     rehearsal = os.environ.get("ASRFE_BENCH_REHEARSAL") == "1"  # every rank on cuda:0 of a one-GPU box (gloo)
@@ -178,9 +184,7 @@ def launch_ranks(n: int) -> int:
     if n_dev < n and not rehearsal:
         print(f"bench.py: --gpus {n} but only {n_dev} GPU(s) are visible", file=sys.stderr)
         return 2
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
+    port = free_port()
     procs = []
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
@@ -242,9 +246,19 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    backend = None
+    # ASRFE_BENCH_FORCE_DIST=1: a single rank still forms an RCCL process group and goes through the barrier and the
+    # reductions (the multi-rank code path of a real node, exercised on a box with one GPU)
+    force_dist = world == 1 and os.environ.get("ASRFE_BENCH_FORCE_DIST") == "1"
+    if world > 1 or force_dist:
         import torch.distributed as dist  # RCCL; used for the barrier and the MAX over ranks only
 
+        if force_dist:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", str(free_port()))
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
+        backend = "gloo" if rehearsal else "nccl"
         if rehearsal:
             dist.init_process_group("gloo")
         else:
@@ -305,6 +319,7 @@ def main():
             "unit": "utt/s",
             "n_gpus": world,
             "ranks_seen": ranks_seen,
+            "collective_backend": backend,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps,
