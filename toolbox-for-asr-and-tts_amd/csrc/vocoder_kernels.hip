@@ -48,7 +48,7 @@ __global__ __launch_bounds__(256, OCC) void conv_tile_kernel(const ConvParams p)
     constexpr int kRowsPerInstr = 64 / kCpr;        // rows one LDS-DMA instruction (1 KiB) covers
     constexpr int kInstrPerWave = NC * 32 / kRowsPerInstr / 4;
     constexpr int kSwzShift = GS == 4 ? 1 : 2;      // rows sharing a 256-byte bank line: 2 (128-byte rows) or 4
-    constexpr int NSTG = OCC == 1 ? 16 : 8;        // 16-byte activation chunks a thread keeps in flight while staging
+    constexpr int NSTG = OCC == 1 ? 16 : 10;       // 16-byte activation chunks a thread keeps in flight while staging
     static_assert(kInstrPerWave >= 1, "ring geometry");
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
