@@ -151,7 +151,13 @@ def cpu_baseline(sd, n_clips: int, batch: int = 8):
         t_one = time.perf_counter() - t0
     finally:
         torch.set_num_threads(nthr)
+    cxx = None
+    try:
+        cxx = cxx_cpu_baseline(sd, nthr)
+    except Exception as e:  # (the C++ restatement is a second opinion: its absence must not cost the bench line)
+        cxx = {"error": f"{type(e).__name__}: {e}"}
     return {
+        "cxx_port": cxx,
         "value": n_clips / (t_front + t_enc),
         "one_thread_value": 1.0 / t_one,
         "unit": "utt/s",
@@ -164,6 +170,32 @@ def cpu_baseline(sd, n_clips: int, batch: int = 8):
         "frontend_s": t_front,
         "encoder_s": t_enc,
     }
+
+
+def cxx_cpu_baseline(sd, threads: int):
+    """The same chain through the C++ restatement of the library's own entry points (oracle/cpu_abi: asrfe_frontend +
+    asrfe_encoder_forward on host pointers, OpenMP, AVX2): 4 clips of 30 s on `threads` threads, then one 10 s clip on
+    one thread scaled to 30 s by its frame count (the encoder's cost per frame grows with the clip, so this flatters
+    the single thread slightly)."""
+    from tests.cpu_abi_util import CpuModel
+    from toolbox_for_asr_and_tts_amd.synth import bench_pcm
+    m = CpuModel(num_blocks=50, state_dict=sd, threads=threads)
+    pcm = bench_pcm(4, SAMPLES, seed=199)
+    t0 = time.perf_counter()
+    feats, lens = m.frontend(pcm, [SAMPLES] * 4)
+    t1 = time.perf_counter()
+    m.encoder(feats, lens)
+    t2 = time.perf_counter()
+    m.set_threads(1)
+    short = SAMPLES // 3
+    t3 = time.perf_counter()
+    f1, l1 = m.frontend(pcm[:1, :short], [short])
+    m.encoder(f1, l1)
+    t_one = (time.perf_counter() - t3) * TP / float(l1[0])
+    m.close()
+    return {"value": 4.0 / (t2 - t0), "one_thread_value": 1.0 / t_one, "unit": "utt/s", "cores": threads, "kind": "port",
+            "frontend_s": t1 - t0, "encoder_s": t2 - t1,
+            "sample": f"4 x 30 s utterances in one call on {threads} threads; one 10 s clip on 1 thread scaled to 30 s"}
 
 
 def free_port() -> int:
