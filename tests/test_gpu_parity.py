@@ -851,3 +851,37 @@ def test_latency_plan_row_limit_and_tile_edges(pkg):
         out, _, _ = enc.forward(feats.cuda(), lt)
         want, _ = so.encoder_forward(feats.double(), lt, {k: v.double() for k, v in sd.items()}, cfg)
         assert float((out.cpu().double() - want).abs().max()) <= ENC_TOL, (b, tp)
+
+
+def test_calls_of_different_sizes_on_one_context_do_not_disturb_each_other(pkg):
+    """One context serves a large engine (throughput plan), a one-utterance engine (latency plan), the head and the
+    allocation-free entry point in turn: every repeat gives the bits of the first call, whatever ran in between."""
+    from toolbox_for_asr_and_tts_amd.decoder import ParaformerHead
+    from oracle import paraformer_decoder_oracle as po
+    nb = 3
+    cfg = pkg.default_config()
+    cfg.enc_num_blocks = nb
+    big = pkg.AsrEngine(batch=40, max_samples=64000, cfg=cfg, state_dict=so.make_state_dict(so.SanmConfig(num_blocks=nb), seed=41))
+    one = pkg.AsrEngine(batch=1, max_samples=40000, ctx=big.ctx)
+    dcfg = po.DecoderConfig(num_blocks=2, vocab_size=300)
+    head = ParaformerHead(big.ctx, num_blocks=2, vocab_size=300)
+    head.load_state_dict(po.make_state_dict(dcfg, seed=42))
+    rng = np.random.default_rng(43)
+    pcm_b = dev(rng.integers(-3000, 3000, size=(40, 64000)).astype(np.int16))
+    len_b = torch.tensor(rng.integers(1000, 64000, size=40).astype(np.int32), device="cuda")
+    pcm_1 = dev(rng.integers(-3000, 3000, size=(1, 40000)).astype(np.int16))
+    len_1 = torch.tensor([40000], dtype=torch.int32, device="cuda")
+
+    def all_calls():
+        ob = big.run(pcm_b, len_b)[0].clone()
+        ids_b = head.forward(big.out, big.feat_lens)["token_ids"].clone()
+        o1 = one.run(pcm_1, len_1)[0].clone()
+        ids_1 = head.forward(one.out, one.feat_lens)["token_ids"].clone()
+        return ob, ids_b, o1, ids_1
+
+    first = all_calls()
+    for _ in range(2):
+        again = all_calls()
+        for a, b in zip(first, again):
+            assert torch.equal(a, b)
+    assert first[0].shape[0] == 40 and big.tp_max * 40 > 2048 and one.tp_max <= 2048  # the two plans were both taken
