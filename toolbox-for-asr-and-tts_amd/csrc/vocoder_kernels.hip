@@ -307,7 +307,7 @@ int64_t conv_lds_bytes(int rows, int stride, int nc) {
     return ((static_cast<int64_t>(rows) * stride + 16 + 127) & ~int64_t{127}) + kConvRingSlots * nc * 32 * 32 * (nc == 4 ? 2 : 4);
 }
 constexpr int kMaxShapes = 5;
-const ConvShape kShapes[3][kMaxShapes] = {{{8, 2}, {4, 2}, {2, 2}, {1, 2}, {0, 0}},   // NC = 1
+const ConvShape kShapes[3][kMaxShapes] = {{{2, 2}, {4, 2}, {8, 2}, {1, 2}, {0, 0}},   // NC = 1 (small tiles: 3-4 workgroups per CU)
                                           {{4, 2}, {2, 2}, {1, 2}, {0, 0}, {0, 0}},   // NC = 2
                                           {{2, 2}, {3, 1}, {2, 1}, {1, 1}, {0, 0}}};  // NC = 4
 
@@ -361,9 +361,14 @@ int32_t launch_conv_mfma(asrfe_ctx* ctx, const ConvParams& pin, hipStream_t s) {
     // of its positions, else the one wasting least
     int pick = -1, best = -1;
     double best_eff = -1.0;
+    // (timing experiments: ASRFE_VOC_SHAPE_NC1 / _NC2 / _NC4 = index of the only shape of the list to consider)
+    static const int forced[3] = {[] { const char* e = getenv("ASRFE_VOC_SHAPE_NC1"); return e ? atoi(e) : -1; }(),
+                                  [] { const char* e = getenv("ASRFE_VOC_SHAPE_NC2"); return e ? atoi(e) : -1; }(),
+                                  [] { const char* e = getenv("ASRFE_VOC_SHAPE_NC4"); return e ? atoi(e) : -1; }()};
+    for (int pass = forced[nci] >= 0 ? 0 : 1; pass < 2 && pick < 0 && best < 0; ++pass)
     for (int k = 0; k < kMaxShapes; ++k) {
         const int cand = kShapes[nci][k].np, occ = kShapes[nci][k].occ, P = 128 * cand;
-        if (!cand || ((ablate & 16) && nc == 4 && occ == 2)) continue;
+        if (!cand || ((ablate & 16) && nc == 4 && occ == 2) || (pass == 0 && forced[nci] != k)) continue;
         const int cit = conv_ci_tile(p.Ci, nc, occ);
         if (!cit || conv_lds_bytes(P + span, 2 * cit + 16, nc) > kConvLdsMax / occ) continue;
         const int tiles = (p.q_count + P - 1) / P;
