@@ -73,6 +73,7 @@ def test_one_utterance_in_every_input_form(pkg, tmp_path):
     assert r_wav[0]["key"] == "utt_7" and r_int[0]["key"] == "rand_key_0"
     assert r_int[0]["token_ids"] == r_flt[0]["token_ids"] == r_ten[0]["token_ids"] == r_wav[0]["token_ids"]
     assert r_int[0]["text"] == r_wav[0]["text"] and len(r_int[0]["token_ids"]) > 3
+    assert r_int[0]["sentence_info"] == [{"text": r_int[0]["text"], "start": 0, "end": 2500, "spk": 0}]
     # a single short utterance went through a batch-1 engine sized for 5 s, not through the batch engine
     assert list(am._one) == [5 * 16000] and am._one[80000].tp_max < am.engine.tp_max
     # 8 s: the next size; too long: refused

@@ -108,8 +108,8 @@ def _read_wav(path: str) -> np.ndarray:
 class AutoModel:
     """``AutoModel(model=<local directory>, device="cuda:0")`` for a Paraformer directory; ``generate(input=...)`` takes
     what the reference passes (a WAV path, a float32 numpy array in [-1, 1] at 16 kHz, an int16 array, a torch tensor, or
-    a list of those) and returns one ``{"key", "text"}`` per utterance (``"token_ids"`` too; text needs the directory's
-    token list).  ``batch`` utterances of up to ``max_seconds`` go through the device at once; longer inputs are refused
+    a list of those) and returns one ``{"key", "text", "sentence_info"}`` per utterance (``"token_ids"`` too; text needs
+    the directory's token list; ``sentence_info`` is the whole utterance as one sentence of speaker 0).  ``batch`` utterances of up to ``max_seconds`` go through the device at once; longer inputs are refused
     (the reference's VAD cuts them into segments first: that model is not part of this package)."""
 
     def __init__(self, model: str, device: str = "cuda:0", batch: int = 16, max_seconds: float = 30.0,
@@ -196,5 +196,10 @@ class AutoModel:
                 ids = self.head.clean_ids(rows[row])
                 item = {"key": keys[i], "token_ids": ids}
                 item["text"] = self.head.ids2text(ids) if self.head.token_list is not None else ""
+                # the reference reads rec_result[0]["sentence_info"] = [{"text", "start" (ms), "end" (ms), "spk"}]
+                # (voice_interface.py:2064-2067, 2092-2093, 2124-2126).  Sentence splitting and speaker labels come from
+                # models that are not part of this package: the utterance is reported as one sentence of speaker 0
+                dur_ms = int(round(1000.0 * clips[i].shape[0] / self.engine.ctx.cfg.sample_rate))
+                item["sentence_info"] = [{"text": item["text"], "start": 0, "end": dur_ms, "spk": 0}] if ids else []
                 results[i] = item
         return results
