@@ -382,11 +382,17 @@ __global__ __launch_bounds__(kWavesPerBlock * 64, 3) void fbank_kernel(const Fba
             v2f sv[13];
             float pv[13];
             v2f sum2 = v2f{0.0f, 0.0f};
+            // the sample in front of a lane's pair is the second sample of the lane before it (DPP rotate within the
+            // frame's 16 lanes: no LDS read); for lane 0 that is lane 15's pair of the row before, and sample 0 stands
+            // in for its own predecessor
+            float ror_prev = 0.0f;
 #pragma unroll
             for (int n1 = 0; n1 < 13; ++n1) {
                 const int i0 = 32 * n1 + 2 * l;
                 const float2 v = *reinterpret_cast<const float2*>(xs + i0);
-                const float pr = xs[i0 > 0 ? i0 - 1 : 0];
+                const float ror = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v.y), 0x121, 0xf, 0xf, false));
+                const float pr = l > 0 ? ror : (n1 > 0 ? ror_prev : v.x);
+                ror_prev = ror;
                 const bool ok = (n1 < 12) || (l < 8);  // sample index < 400
                 sv[n1] = ok ? v2f{v.x, v.y} : v2f{0.0f, 0.0f};
                 pv[n1] = ok ? pr : 0.0f;

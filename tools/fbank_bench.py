@@ -28,8 +28,11 @@ def main():
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--repeat", type=int, default=3)
     ap.add_argument("--batch", type=int, default=256)
+    ap.add_argument("--lib", default=None, help="path of another build of libasrfe.so (A/B runs of experiment builds)")
     ap.add_argument("--bench-pcm", action="store_true", help="use bench.py's synthetic PCM (10 % leading zeros per clip)")
     args = ap.parse_args()
+    if args.lib:
+        _lib.LIB_PATH = os.path.abspath(args.lib)
     fe = pkg.WavFrontend()
     dev = "cuda"
     if args.check:
