@@ -237,7 +237,43 @@ int32_t asrfe_vocoder_hop(const asrfe_ctx* ctx);
 int32_t asrfe_vocoder_forward(asrfe_ctx* ctx, const float* mel, int32_t batch, int32_t t_mel, float* wav, void* workspace,
                               int64_t workspace_bytes, void* stream);
 
-/* The same forward for callers that cannot allocate device memory (code under HIP graph capture, tight serving
+/* ---- FSMN voice-activity network (frame scores for the speech / silence detector) ----------------------------------
+ * Stands in for the network inside the reference's per-chunk call vad_model.generate(input=audio_np, cache=self.vad_cache,
+ * is_final=False, chunk_size=...) (voice-service/app/services/voice_interface.py:1585-1590; the model is loaded at
+ * :723-727): FunASR's FSMN encoder of speech_fsmn_vad_zh-cn-16k-common-pytorch.  The features come from asrfe_fbank +
+ * asrfe_lfr_cmvn of a context created with lfr_m = 5, lfr_n = 1 and the model's own CMVN; the detector that turns frame
+ * scores into [begin, end] segments is sequential host logic (the Python mirror carries it). */
+typedef struct asrfe_vad_config {
+    int32_t input_dim;         /* 400 = lfr_m 5 x 80 mel (a multiple of 8) */
+    int32_t input_affine_dim;  /* 140 */
+    int32_t fsmn_layers;       /* 4 */
+    int32_t linear_dim;        /* 250 */
+    int32_t proj_dim;          /* 128 (<= 256) */
+    int32_t lorder;            /* 20 causal taps (<= 33); rorder 0 and stride 1 only */
+    int32_t output_affine_dim; /* 140 */
+    int32_t output_dim;        /* 248 classes; class 0 is silence */
+} asrfe_vad_config;
+int32_t asrfe_default_vad_config(asrfe_vad_config* cfg);
+/* model.pt tensors under FunASR's names (host float32): encoder.in_linear1.linear.{weight,bias}, encoder.in_linear2...,
+ * encoder.fsmn.I.linear.linear.weight, encoder.fsmn.I.fsmn_block.conv_left.weight [proj, 1, lorder, 1],
+ * encoder.fsmn.I.affine.linear.{weight,bias}, encoder.out_linear1..., encoder.out_linear2....  The products run with
+ * operands in the context's enc_compute_dtype (conversions to fp16 saturate). */
+int32_t asrfe_load_vad_weights(asrfe_ctx* ctx, const asrfe_vad_config* cfg, const asrfe_tensor_desc* descs, int32_t n);
+int64_t asrfe_vad_workspace_bytes(const asrfe_ctx* ctx, int32_t batch, int32_t t);
+/* floats of cache one stream needs: fsmn_layers x (lorder - 1) x proj_dim (the rows in front of the next chunk) */
+int64_t asrfe_vad_cache_floats(const asrfe_ctx* ctx);
+/* FSMN.forward: feats [B, t, input_dim] float32, lens [B] int32 or NULL (= t rows each) -> scores [B, t, output_dim]
+ * float32 (softmax; rows >= lens[b] hold no meaning).  cache [B, asrfe_vad_cache_floats] float32 or NULL: the memory
+ * blocks read it as the rows before the chunk and the call leaves the last lorder - 1 rows of (cache ++ the chunk's
+ * lens[b] rows) in it; zeros start a stream; with NULL every call starts from silence. */
+int32_t asrfe_vad_forward(asrfe_ctx* ctx, const float* feats, const int32_t* lens, int32_t batch, int32_t t, float* cache,
+                          float* scores, void* workspace, int64_t workspace_bytes, void* stream);
+/* The level the detector reads beside the scores (E2EVadModel.ComputeDecibel): decibel [B, t_max] float32 =
+ * 10 log10(sum over the frame's 400 samples of x^2 + 1e-6) with x in [-1, 1]; 0 for rows past a clip's frames. */
+int32_t asrfe_frame_decibel(asrfe_ctx* ctx, const void* pcm, int32_t pcm_dtype, int64_t pcm_stride, const int32_t* pcm_lens,
+                            int32_t batch, int32_t t_max, float* decibel, void* stream);
+
+/* asrfe_encoder_forward for callers that cannot allocate device memory (code under HIP graph capture, tight serving
  * loops, harnesses that forbid hipMalloc): no workspace argument.  No counterpart in the reference.  The scratch is a
  * device array inside the library, ASRFE_STATIC_SCRATCH_BYTES per GPU for the life of the process; a [batch, tp]
  * call needs asrfe_encoder_workspace_bytes(ctx, batch, tp) of it (about 8.3 KiB per row: up to ~3970 rows, e.g.

@@ -155,3 +155,38 @@ def test_streaming_session_known_sequence():
     assert ses.process_chunk(q(0.003), 3.19)["should_finalize"] is False
     assert ses.process_chunk(q(0.003), 3.2)["should_finalize"] is True
     assert len(ses.audio) == 12800 + 2 * 6400
+
+
+def test_session_asks_the_vad_model_per_chunk_and_decides_by_energy():
+    """voice_interface.py:1585-1606: generate(input=chunk, cache=session cache, is_final=False, chunk_size=ms); the answer is
+    read from [{"value": [...]}] and the decision stays the energy rule's; a failing model changes nothing."""
+    calls = []
+
+    class FakeVad:
+        def __init__(self):
+            self.fail = False
+
+        def generate(self, input, cache, is_final, chunk_size):
+            if self.fail:
+                raise RuntimeError("model down")
+            calls.append((len(input), id(cache), is_final, chunk_size))
+            return [{"key": "k", "value": [[0, -1]] if np.abs(input).max() > 0.01 else []}]
+
+    vad = FakeVad()
+    ses = ing.StreamingPcmSession(device="cpu", now=0.0, vad_model=vad)
+    quiet = np.full(6400, 0.02, np.float32)          # the model says speech, the energy rule says no
+    st = ses.process_chunk(quiet, now=0.4)
+    assert st["is_speech"] is False and ses.is_speech_vad is True
+    loud = np.full(6400, 0.2, np.float32)
+    st = ses.process_chunk(loud, now=0.8)
+    assert st["is_speech"] is True and ses.is_speech_vad is True
+    assert ses.process_chunk(np.zeros(3200, np.float32), now=1.0)["is_speech"] is False and ses.is_speech_vad is False
+    assert [c[0] for c in calls] == [6400, 6400, 3200] and [c[3] for c in calls] == [400, 400, 200]
+    assert all(c[2] is False for c in calls) and len({c[1] for c in calls}) == 1      # one cache for the session
+    cache_before = calls[-1][1]
+    ses.reset(now=2.0)
+    ses.process_chunk(loud, now=2.4)
+    assert calls[-1][1] != cache_before               # reset starts a new VAD stream
+    vad.fail = True
+    st = ses.process_chunk(loud, now=2.8)
+    assert st["is_speech"] is True and ses.is_speech_vad is False

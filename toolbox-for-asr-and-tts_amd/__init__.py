@@ -10,7 +10,8 @@ from .encoder import SANMEncoder  # noqa: F401
 from .engine import AsrEngine, shard_by_length, shard_range  # noqa: F401
 from .decoder import ParaformerHead  # noqa: F401
 from .model_dir import AutoModel, read_model_dir  # noqa: F401
+from .vad import FsmnVadModel, FsmnVadNet, VadDetector, VadOptions  # noqa: F401
 from .ingress import PcmAccumulator, StreamingPcmSession, decode_wav_base64, wire_int16  # noqa: F401
 
 __all__ = ["AsrfeError", "Config", "Context", "default_config", "load", "WavFrontend", "load_cmvn",
-           "SANMEncoder", "ParaformerHead", "AutoModel", "read_model_dir", "AsrEngine", "shard_range", "shard_by_length", "PcmAccumulator", "StreamingPcmSession", "decode_wav_base64", "wire_int16"]
+           "SANMEncoder", "ParaformerHead", "AutoModel", "read_model_dir", "FsmnVadModel", "FsmnVadNet", "VadDetector", "VadOptions", "AsrEngine", "shard_range", "shard_by_length", "PcmAccumulator", "StreamingPcmSession", "decode_wav_base64", "wire_int16"]

@@ -88,6 +88,19 @@ class VocoderConfig(C.Structure):
     ]
 
 
+class VadConfig(C.Structure):
+    _fields_ = [
+        ("input_dim", C.c_int32),
+        ("input_affine_dim", C.c_int32),
+        ("fsmn_layers", C.c_int32),
+        ("linear_dim", C.c_int32),
+        ("proj_dim", C.c_int32),
+        ("lorder", C.c_int32),
+        ("output_affine_dim", C.c_int32),
+        ("output_dim", C.c_int32),
+    ]
+
+
 PROF_KINDS = ["fbank", "frontend", "lfr_cmvn", "pe_table", "layernorm", "gemm_qkv", "fsmn", "attention", "gemm_out",
               "gemm_ffn1", "gemm_ffn2", "post_attn"]
 
@@ -139,6 +152,14 @@ SIGNATURES = {
     "asrfe_vocoder_hop": (C.c_int32, [C.c_void_p]),
     "asrfe_vocoder_forward": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_int64,
                                           C.c_void_p]),
+    "asrfe_default_vad_config": (C.c_int32, [C.POINTER(VadConfig)]),
+    "asrfe_load_vad_weights": (C.c_int32, [C.c_void_p, C.POINTER(VadConfig), C.POINTER(TensorDesc), C.c_int32]),
+    "asrfe_vad_workspace_bytes": (C.c_int64, [C.c_void_p, C.c_int32, C.c_int32]),
+    "asrfe_vad_cache_floats": (C.c_int64, [C.c_void_p]),
+    "asrfe_vad_forward": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,
+                                      C.c_void_p, C.c_int64, C.c_void_p]),
+    "asrfe_frame_decibel": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int64, C.c_void_p, C.c_int32, C.c_int32,
+                                        C.c_void_p, C.c_void_p]),
     "asrfe_host_mel_banks": (C.c_int32, [C.POINTER(Config), C.POINTER(C.c_double)]),
     "asrfe_host_window": (C.c_int32, [C.POINTER(Config), C.POINTER(C.c_double)]),
     "asrfe_profile_begin": (C.c_int32, [C.c_void_p, C.c_int32]),

@@ -312,6 +312,7 @@ extern "C" int32_t asrfe_destroy(asrfe_ctx* ctx) {
     for (hipEvent_t e : ctx->prof_events) (void)hipEventDestroy(e);
     free_decoder(ctx);
     free_vocoder(ctx);
+    free_vad(ctx);
     for (void* p : ctx->owned) (void)hipFree(p);
     delete ctx;
     return ASRFE_OK;

@@ -12,6 +12,7 @@
 namespace asrfe {
 struct DecoderWeights;  // decoder.h
 struct VocoderWeights;  // vocoder.h
+struct VadWeights;      // vad.h
 
 // ---- frontend geometry the kernels are built for -------------------------------------------
 constexpr int kFrameLen = 400;
@@ -90,6 +91,7 @@ struct asrfe_ctx {
     float* pe_inv;  // [input_size/2] inverse timescales of the sinusoidal position code
     asrfe::VocoderWeights* voc = nullptr;  // HiFi-GAN generator weights (asrfe_load_vocoder_weights), else null
     asrfe::DecoderWeights* dec = nullptr;  // CIF predictor + decoder weights (asrfe_load_decoder_weights), else null
+    asrfe::VadWeights* vad = nullptr;      // FSMN voice-activity network (asrfe_load_vad_weights), else null
     std::vector<void*> owned;  // every device allocation, freed in asrfe_destroy
     // optional per-kernel event timing (asrfe_profile_begin / _end)
     bool prof_on = false;
@@ -124,6 +126,7 @@ int32_t launch_lfr_cmvn(asrfe_ctx* ctx, const float* logmel, const int32_t* n_fr
                         int tp_max, void* feats, int out_dtype, int32_t* lens_out, hipStream_t s);
 void free_vocoder(asrfe_ctx* ctx);  // vocoder.cpp
 void free_decoder(asrfe_ctx* ctx);  // decoder.cpp: drops the predictor / decoder weight table (device memory is in `owned`)
+void free_vad(asrfe_ctx* ctx);      // vad.cpp
 int32_t prepare_static_scratch(asrfe_ctx* ctx);  // static_scratch.hip: device address of the library's scratch array
 int64_t encoder_workspace_bytes(const asrfe_ctx* ctx, int batch, int tp);
 int32_t encoder_forward(asrfe_ctx* ctx, const float* feats, const int32_t* lens, int batch, int tp, void* out,

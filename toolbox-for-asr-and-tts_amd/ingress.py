@@ -104,8 +104,11 @@ class StreamingPcmSession:
     (voice_interface.py: state :1103-1116, ``process_chunk`` :1569-1578, :1606, :1672-1747, :1816-1818), with the
     utterance held on the device:
 
-    * a chunk counts as speech when mean|x| > 0.03 and max|x| > 0.17 (the reference also asks its VAD model but
-      discards the answer, :1605-1606; no model is consulted here);
+    * a chunk counts as speech when mean|x| > 0.03 and max|x| > 0.17.  The reference also asks its VAD model per chunk
+      (``vad_model.generate(input=chunk, cache=self.vad_cache, is_final=False, chunk_size=ms)``, :1585-1600) and then
+      decides by the energy rule alone (:1605-1606).  With ``vad_model`` given (``AutoModel`` of an FSMN-VAD directory)
+      the same call is made here, a failing call falls back to the energy rule as there (:1601-1602), and the answer is
+      kept in ``is_speech_vad``; the decision stays the energy rule's;
     * before the first speech chunk only the newest 400 ms are kept (host side, at most 6400 samples) and they are
       put in front of that first speech chunk;
     * after speech, every speech chunk and at most two silent chunks in a row are appended;
@@ -119,10 +122,11 @@ class StreamingPcmSession:
     SILENCE_THRESHOLD = 2.0
     PRE_SPEECH_MAX_DURATION = 0.4
 
-    def __init__(self, device="cuda", capacity: int = 16000 * 30, now: float | None = None):
+    def __init__(self, device="cuda", capacity: int = 16000 * 30, now: float | None = None, vad_model=None):
         import time
         self._clock = time.time
         self.audio = PcmAccumulator(device, capacity)
+        self.vad_model = vad_model
         self.reset(now)
 
     def reset(self, now: float | None = None):
@@ -132,12 +136,29 @@ class StreamingPcmSession:
         self.last_voice_time = self._clock() if now is None else now
         self.has_detected_speech = False
         self.silence_chunk_count = 0
+        self.vad_cache = {}           # the reference clears it with the session state (voice_interface.py:1157, 1262)
+        self.is_speech_vad = False
+
+    def _ask_vad(self, x) -> bool:
+        try:
+            res = self.vad_model.generate(input=x, cache=self.vad_cache, is_final=False,
+                                          chunk_size=int(len(x) / TARGET_SAMPLE_RATE * 1000))
+            if isinstance(res, list) and res and isinstance(res[0], dict):
+                value = res[0].get("value", [])
+                if isinstance(value, list):
+                    return len(value) > 0
+                if isinstance(value, str):
+                    return value.lower() == "speech"
+        except Exception:  # the reference logs a warning and goes on with the energy rule
+            pass
+        return False
 
     def process_chunk(self, audio_np, now: float | None = None):
         now = self._clock() if now is None else now
         x = np.asarray(audio_np)
         mag = np.abs(x)
         is_speech = bool(np.mean(mag) > self.VAD_ENERGY_THRESHOLD and np.max(mag) > self.VAD_MAX_THRESHOLD)
+        self.is_speech_vad = self._ask_vad(x) if self.vad_model is not None and x.size else False
         if is_speech:
             self.silence_timer = 0.0
             self.last_voice_time = now

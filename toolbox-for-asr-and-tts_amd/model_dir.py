@@ -6,6 +6,7 @@ A model directory of the ModelScope / FunASR layout holds
     config.yaml   frontend_conf / encoder_conf / predictor_conf / decoder_conf (and optionally ``token_list``)
     am.mvn        CMVN statistics (Kaldi nnet text: <AddShift>, <Rescale>)
     model.pt      the checkpoint: a ``state_dict`` (possibly under the key "state_dict" or "model")
+(an FSMN-VAD directory holds ``vad.mvn`` instead of ``am.mvn`` and no token list)
     tokens.json   the token list (or tokens.txt, one token per line)
 Nothing is executed from those files: YAML is read with the safe loader, the checkpoint with
 ``torch.load(weights_only=True)``.  Everything runs on the device through libasrfe; there is no CPU path."""
@@ -38,8 +39,9 @@ def read_model_dir(path: str) -> dict:
     if not isinstance(config, dict):
         raise ValueError(f"{cfg_file}: not a mapping")
     cmvn_file = os.path.join(path, str((config.get("frontend_conf") or {}).get("cmvn_file") or "am.mvn"))
-    if not os.path.isfile(cmvn_file):
-        cmvn_file = os.path.join(path, "am.mvn")
+    for name in ("am.mvn", "vad.mvn"):
+        if not os.path.isfile(cmvn_file):
+            cmvn_file = os.path.join(path, name)
     cmvn = load_cmvn(cmvn_file)
     tokens = None
     for name in ("tokens.json", "tokens.txt"):
@@ -64,6 +66,11 @@ def read_model_dir(path: str) -> dict:
     if not isinstance(ckpt, dict) or not any(k.startswith("encoder.") for k in ckpt):
         raise ValueError(f"{path}: the checkpoint holds no encoder.* tensors")
     return {"config": config, "cmvn": cmvn, "tokens": tokens, "state_dict": ckpt}
+
+
+def is_vad_config(config: dict) -> bool:
+    """True for a config.yaml of FunASR's streaming FSMN voice-activity model."""
+    return str(config.get("model", "")).startswith("FsmnVAD") or str(config.get("encoder", "")) == "FSMN"
 
 
 def library_config(config: dict, small_batch_rows: int | None = None) -> _lib.Config:
@@ -120,6 +127,13 @@ class AutoModel:
         self.model_path = model
         self.device = torch.device(device)
         self.kwargs = parts["config"]
+        self._vad = None
+        if is_vad_config(parts["config"]):
+            # the streaming voice-activity model (voice_interface.py:723-727): its generate() takes the per-chunk
+            # arguments the reference passes at :1585-1590
+            from .vad import FsmnVadModel
+            self._vad = FsmnVadModel(parts["config"], parts["cmvn"], parts["state_dict"], device=self.device)
+            return
         cfg = library_config(parts["config"], small_batch_rows)
         self.max_samples = int(max_seconds * cfg.sample_rate)
         sd = parts["state_dict"]
@@ -171,7 +185,9 @@ class AutoModel:
         # a WAV file of the same signal would hold
         return np.clip(np.rint(a.astype(np.float64) * 32768.0), -32768, 32767).astype(np.int16)
 
-    def generate(self, input, cache=None, is_final: bool = True, **kwargs) -> list:
+    def generate(self, input, cache=None, is_final: bool | None = None, **kwargs) -> list:
+        if self._vad is not None:
+            return self._vad.generate(input, cache=cache, is_final=is_final, **kwargs)
         items = list(input) if isinstance(input, (list, tuple)) else [input]
         keys = [os.path.splitext(os.path.basename(x))[0] if isinstance(x, str) else f"rand_key_{i}" for i, x in enumerate(items)]
         clips = [self._to_int16(x) for x in items]

@@ -123,11 +123,14 @@ def head_decoder(head) -> Callable:
     return decode
 
 
-def create_app(engine, decoder: Optional[Callable] = None, clock: Optional[Callable[[], float]] = None, head=None) -> FastAPI:
+def create_app(engine, decoder: Optional[Callable] = None, clock: Optional[Callable[[], float]] = None, head=None,
+               vad_model=None) -> FastAPI:
     """``clock``: the time source of the streaming sessions' silence timer (``time.time`` by default).
     ``engine``: an ``AsrEngine(batch=1, max_samples=...)`` (anything with ``run``, ``device`` and
     ``max_samples`` serves, which is how the CPU tests drive the route).  ``head``: a loaded ``ParaformerHead`` on the
-    engine's context; it becomes the decoder when no ``decoder`` callable is given."""
+    engine's context; it becomes the decoder when no ``decoder`` callable is given.  ``vad_model``: ``AutoModel`` of an
+    FSMN-VAD directory; the streaming sessions then ask it once per chunk, as the reference's sessions do
+    (voice_interface.py:1585-1590)."""
     if decoder is None and head is not None:
         decoder = head_decoder(head)
     app = FastAPI(title="voice")
@@ -167,7 +170,7 @@ def create_app(engine, decoder: Optional[Callable] = None, clock: Optional[Calla
         now = clock or time.time
         await websocket.accept()
         try:
-            session = StreamingPcmSession(device=engine.device, now=now())
+            session = StreamingPcmSession(device=engine.device, now=now(), vad_model=vad_model)
         except Exception as e:
             await websocket.send_json({"type": "error", "message": f"session creation failed: {e}",
                                        "code": "SESSION_CREATE_ERROR"})

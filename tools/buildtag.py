@@ -1,5 +1,5 @@
 """Tag of the kernel sources a measurement was taken with: sha256 over the files of csrc/ that the frontend and encoder
-kernels are built from (the decoder's and the vocoder's own files are left out: no counter profile covers them) and
+kernels are built from (the decoder's, the vocoder's and the voice-activity network's own files are left out: no counter profile covers them) and
 include/asrfe.h.  Counter profiles under profiles/ record it; bench.py only quotes a profile whose tag equals that of
 the tree it runs from, so numbers of an older build cannot be mistaken for this one's."""
 import glob
@@ -14,7 +14,7 @@ def csrc_tag() -> str:
     files = sorted(glob.glob(os.path.join(ROOT, "toolbox-for-asr-and-tts_amd", "csrc", "*")))
     files.append(os.path.join(ROOT, "include", "asrfe.h"))
     for f in files:
-        if os.path.basename(f).startswith(("decoder", "vocoder")):
+        if os.path.basename(f).startswith(("decoder", "vocoder", "vad")):
             continue
         if os.path.isfile(f) and f.endswith((".hip", ".cpp", ".h", "Makefile")):
             h.update(os.path.basename(f).encode())
