@@ -139,3 +139,29 @@ def vocoder_flops(t_mel: int, initial_channel: int = 512, n_mels: int = 80, rate
             fl += 6 * 2.0 * t * co * co * rk
         ch = co
     return fl + 2.0 * t * ch * 7
+
+
+def vad_state_dict(input_dim: int = 400, input_affine_dim: int = 140, fsmn_layers: int = 4, linear_dim: int = 250,
+                   proj_dim: int = 128, lorder: int = 20, output_affine_dim: int = 140, output_dim: int = 248,
+                   seed: int = 0) -> dict:
+    """Random-init weights of the FSMN voice-activity network under FunASR's names (``encoder.*``)."""
+    g = torch.Generator().manual_seed(seed)
+
+    def lin(n, k):
+        return torch.randn(n, k, generator=g) / float(np.sqrt(k))
+
+    sd = {"encoder.in_linear1.linear.weight": lin(input_affine_dim, input_dim),
+          "encoder.in_linear1.linear.bias": 0.1 * torch.randn(input_affine_dim, generator=g),
+          "encoder.in_linear2.linear.weight": lin(linear_dim, input_affine_dim),
+          "encoder.in_linear2.linear.bias": 0.1 * torch.randn(linear_dim, generator=g)}
+    for i in range(fsmn_layers):
+        p = f"encoder.fsmn.{i}"
+        sd[p + ".linear.linear.weight"] = lin(proj_dim, linear_dim)
+        sd[p + ".fsmn_block.conv_left.weight"] = 0.1 * torch.randn(proj_dim, 1, lorder, 1, generator=g)
+        sd[p + ".affine.linear.weight"] = lin(linear_dim, proj_dim)
+        sd[p + ".affine.linear.bias"] = 0.1 * torch.randn(linear_dim, generator=g)
+    sd["encoder.out_linear1.linear.weight"] = lin(output_affine_dim, linear_dim)
+    sd["encoder.out_linear1.linear.bias"] = 0.1 * torch.randn(output_affine_dim, generator=g)
+    sd["encoder.out_linear2.linear.weight"] = lin(output_dim, output_affine_dim)
+    sd["encoder.out_linear2.linear.bias"] = 0.1 * torch.randn(output_dim, generator=g)
+    return sd
