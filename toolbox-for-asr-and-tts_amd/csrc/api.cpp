@@ -1,5 +1,6 @@
 // libasrfe C ABI: context, device tables, weight loading and argument checking.
 // The compute calls only validate, fill a parameter block and launch; they never allocate.
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -227,11 +228,55 @@ extern "C" int32_t asrfe_create(const asrfe_config* cfg, asrfe_ctx** out) {
     if (cfg->low_freq <= 0.0f) {
         return fail(set_err(ctx, ASRFE_ERR_BAD_ARG, "asrfe_create: low_freq must be > 0 (the DC bin is not computed)"));
     }
+    // Where a filter's window starts is free as long as its non-zero terms stay inside: a group's windows are as wide
+    // as its widest filter rounded up to 4 terms, and a term in front of a filter's first bin has weight zero.  The
+    // kernel's gather reads one term of 32 lanes (the 16 filters of a group in two frames) per LDS pass over 32 banks,
+    // with the power row of every other frame 16 floats further on: the pass is free of bank conflicts exactly when
+    // the different start bins of a group differ modulo 16.  The starts are moved down (by at most the slack of the
+    // window, never below bin 1) to make them so; when a group's own width leaves too little room, one more chunk
+    // of 4 terms does (20 conflict-free passes beat 16 two-way ones).
+    std::vector<int> shift(kMelGroups * 16, 0);
+    auto spread = [&](int g, int gw) -> bool {
+        int lo[16], hi[16], order[16];
+        for (int l = 0; l < 16; ++l) {
+            const int st = start[g * 16 + l], w = width[g * 16 + l];
+            if (w == 0) { lo[l] = 1; hi[l] = 16; }  // an unused lane reads zero weights: any window will do
+            else { hi[l] = st; lo[l] = std::max(1, st - (gw - w)); }
+            order[l] = l;
+        }
+        std::sort(order, order + 16, [&](int a, int b) { return hi[a] - lo[a] < hi[b] - lo[b]; });
+        int owner[16], pick[16];
+        std::fill(owner, owner + 16, -1);
+        long budget = 2000000;  // (search steps; the layouts in use need a few hundred)
+        auto place = [&](auto&& self, int i) -> bool {
+            if (i == 16) return true;
+            if (--budget < 0) return false;
+            const int l = order[i];
+            for (int st = hi[l]; st >= lo[l]; --st) {
+                const int r = st & 15;
+                if (owner[r] != -1 && owner[r] != st) continue;
+                const int before = owner[r];
+                owner[r] = st;
+                pick[l] = st;
+                if (self(self, i + 1)) return true;
+                owner[r] = before;
+            }
+            return false;
+        };
+        if (!place(place, 0)) return false;
+        for (int l = 0; l < 16; ++l) {
+            shift[g * 16 + l] = width[g * 16 + l] ? start[g * 16 + l] - pick[l] : 0;
+            if (!width[g * 16 + l]) start[g * 16 + l] = pick[l];
+        }
+        return true;
+    };
     int total = 0;
     for (int g = 0; g < kMelGroups; ++g) {
         int gw = 0;
         for (int l = 0; l < 16; ++l) gw = std::max(gw, width[g * 16 + l]);
         gw = (gw + 3) / 4 * 4;
+        int room = kMelMaxTerms - total - gw;  // terms the later groups need at least are not known yet: checked below
+        if (!spread(g, gw) && room >= 4 && spread(g, gw + 4)) gw += 4;
         ctx->tab.mel_gw[g] = gw;
         ctx->tab.mel_go[g] = total;
         total += gw;
@@ -244,10 +289,10 @@ extern "C" int32_t asrfe_create(const asrfe_config* cfg, asrfe_ctx** out) {
     for (int g = 0; g < kMelGroups; ++g)
         for (int l = 0; l < 16; ++l) {
             const int m = g * 16 + l;
-            msb[g * 16 + l] = start[g * 16 + l];
+            msb[g * 16 + l] = start[g * 16 + l] - shift[g * 16 + l];
             if (m >= cfg->n_mels) continue;
             for (int j = 0; j < width[g * 16 + l]; ++j) {
-                const int term = ctx->tab.mel_go[g] + j;  // chunk term / 4, lane l, element term % 4
+                const int term = ctx->tab.mel_go[g] + shift[g * 16 + l] + j;  // chunk term / 4, lane l, element term % 4
                 mw[((term / 4) * 16 + l) * 4 + term % 4] =
                     static_cast<float>(0.25 * banks[static_cast<size_t>(m) * nb + start[g * 16 + l] + j]);
             }

@@ -55,7 +55,8 @@ __device__ __forceinline__ float row16_sum(float v) {
 }
 
 // 4-term chunks per mel group (filters lane + 16 g) of the standard layout: 80 filters, 20 Hz .. 8 kHz, 512-point FFT
-__device__ __host__ constexpr int std_mel_chunks(int g) { return g == 0 ? 1 : g == 1 ? 1 : g == 2 ? 2 : g == 3 ? 3 : 4; }
+// (the last group's windows are one chunk wider than its widest filter: room to start them on different banks)
+__device__ __host__ constexpr int std_mel_chunks(int g) { return g == 0 ? 1 : g == 1 ? 1 : g == 2 ? 2 : g == 3 ? 3 : 5; }
 __device__ __host__ constexpr int std_mel_first(int g) { return g == 0 ? 0 : g == 1 ? 1 : g == 2 ? 2 : g == 3 ? 4 : 7; }
 
 // Complex numbers travel as packed fp32 pairs (re, im) through v_pk_add / v_pk_mul / v_pk_fma_f32.  The half
