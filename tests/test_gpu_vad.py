@@ -232,3 +232,22 @@ def test_streaming_session_with_the_vad_model(pkg, tmp_path):
     assert "_stream" in ses.vad_cache
     ses.reset(now=10.0)
     assert ses.vad_cache == {}
+
+
+def test_many_streams_at_once_equal_single_streams(pkg):
+    """64 streams x 1000 frames in one call (250 row tiles per product, every CU busy): a stream's scores and cache do not
+    depend on its position in the batch or on its neighbours, to the last bit; and they match the oracle."""
+    sd = vo.make_state_dict(seed=21)
+    net = make_net(pkg, sd)
+    g = torch.Generator().manual_seed(7)
+    x = torch.randn(64, 1000, 400, generator=g)
+    lens = [1000 - 13 * (i % 7) for i in range(64)]
+    cache = net.new_cache(64, "cuda")
+    s = net(x.cuda(), lens=lens, cache=cache).cpu()
+    for b in (0, 31, 63):
+        c1 = net.new_cache(1, "cuda")
+        s1 = net(x[b:b + 1, :lens[b]].contiguous().cuda(), cache=c1).cpu()
+        assert torch.equal(s[b, :lens[b]], s1[0])
+        assert torch.equal(cache[b].cpu(), c1[0].cpu())
+    want, _ = vo.fsmn_forward(sd, x[31, :lens[31]].numpy())
+    assert np.abs(s[31, :lens[31]].numpy() - want).max() < TOL_F16
