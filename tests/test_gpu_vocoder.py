@@ -78,6 +78,26 @@ def test_generator_long_inputs_match_oracle(pkg, cfg, t_mel):
     print(f"channels {cfg.initial_channel}, {t_mel} frames: max waveform error {err:.3e}")
 
 
+@pytest.mark.parametrize("cfg,t_mel", [
+    (ho.HifiganConfig(), 94),                                                                            # 64- and 32-channel stages fused
+    (ho.HifiganConfig(initial_channel=128, upsample_rates=(2, 2), upsample_kernels=(4, 4)), 701),     # both stages fused
+    (ho.HifiganConfig(initial_channel=64, upsample_rates=(3,), upsample_kernels=(9,), resblock_kernels=(5, 13),
+                      resblock_dilations=((1, 2, 7), (2, 1, 4))), 333),                                # other widths and dilations
+])
+def test_fused_pairs_equal_the_two_launch_form(pkg, cfg, t_mel, monkeypatch):
+    """Stages of 32 and 64 channels run a residual pair as one launch; its arithmetic (operand rounding, accumulation
+    order) is that of the two launches, so the waveforms are equal bit for bit."""
+    gen, sd = build(cfg, seed=17)
+    mel = torch.randn(3, cfg.n_mels, t_mel, generator=torch.Generator().manual_seed(t_mel + 1)).cuda()
+    monkeypatch.setenv("ASRFE_VOC_NO_FUSE", "1")
+    two = gen.forward(mel).clone()
+    monkeypatch.setenv("ASRFE_VOC_NO_FUSE", "0")
+    one = gen.forward(mel).clone()
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(one).all()) and float(one.abs().max()) > 0.05
+    assert torch.equal(one, two)
+
+
 def test_generator_fixture(pkg):
     import os
     g = np.load(os.path.join(os.path.dirname(__file__), "golden", "vocoder_tiny.npz"))

@@ -8,6 +8,7 @@
 #include "vocoder.h"
 
 #include <cstdio>
+#include <cstdlib>
 
 #include "weights.h"
 
@@ -213,12 +214,22 @@ extern "C" int32_t asrfe_vocoder_forward(asrfe_ctx* ctx, const float* mel, int32
     for (size_t i = 0; i < W.stages.size(); ++i) {
         const VocoderWeights::Stage& S = W.stages[i];
         const int Tout = T * S.u;
+        // Stages with few channels run every residual pair as one launch on the f32 stream (no 16-bit copies between
+        // the convolutions); ASRFE_VOC_NO_FUSE=1 keeps the two-launch form everywhere (the tests compare the two)
+        const char* nf = getenv("ASRFE_VOC_NO_FUSE");  // (read per call: a test switches it inside one process)
+        bool fused = !(nf && atoi(nf) != 0);
+        for (int j = 0; j < nrb * 3 && fused; ++j) {
+            const VocConv &a = S.c1[j], &c = S.c2[j];
+            fused = a.Ci == S.Co && a.Co == S.Co && c.Ci == S.Co && c.Co == S.Co && a.k == c.k && c.dil == 1 &&
+                    conv_pair_supported(S.Co, a.k, a.dil);
+        }
         {   // transposed convolution: u phases of k / u taps; raw result to the residual stream, activated copy beside it
+            // (nobody reads the copy in a fused stage)
             ConvParams p{};
             p.x = b.a[0]; p.w = S.up_w; p.bias = S.up_b; p.B = batch; p.Tin = T; p.Ci = S.Ci; p.Co = S.Co; p.taps = S.k / S.u;
             p.off0 = 0; p.dtap = -1; p.phases = S.u; p.q_count = T + 1;
             p.out_mul = S.u; p.out_add0 = -((S.k - S.u) / 2); p.out_add_step = 1; p.Tout = Tout;
-            p.slope = slope; p.y16 = b.a[1]; p.res_out = b.r[0];
+            p.slope = slope; p.y16 = fused ? nullptr : b.a[1]; p.res_out = b.r[0];
             if ((rc = launch_conv_mfma(ctx, p, s))) return rc;
         }
         T = Tout;
@@ -226,9 +237,14 @@ extern "C" int32_t asrfe_vocoder_forward(asrfe_ctx* ctx, const float* mel, int32
             const float* xr = b.r[0];
             const uint16_t* xa = b.a[1];
             for (int q = 0; q < 3; ++q) {
-                if ((rc = conv(S.c1[j * 3 + q], xa, T, slope, b.a[0], nullptr, nullptr))) return rc;
                 const bool last = q == 2;  // the block's output goes to its own buffer; nothing reads its activated copy
                 float* ro = last ? b.out[j] : b.r[1 + (q & 1)];
+                if (fused) {
+                    if ((rc = launch_conv_pair(ctx, xr, ro, S.c1[j * 3 + q], S.c2[j * 3 + q], batch, T, slope, s))) return rc;
+                    xr = ro;
+                    continue;
+                }
+                if ((rc = conv(S.c1[j * 3 + q], xa, T, slope, b.a[0], nullptr, nullptr))) return rc;
                 uint16_t* ao = last ? nullptr : b.a[2 + (q & 1)];
                 if ((rc = conv(S.c2[j * 3 + q], b.a[0], T, slope, ao, xr, ro))) return rc;
                 xr = ro;

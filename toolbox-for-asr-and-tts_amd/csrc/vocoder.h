@@ -46,6 +46,11 @@ struct VocoderWeights {
 };
 
 int32_t launch_conv_mfma(asrfe_ctx* ctx, const ConvParams& p, hipStream_t s);
+// a residual pair (dilated convolution, plain convolution, both C -> C over k taps) as one launch on the f32 stream:
+// out = x + conv2(lrelu(conv1(lrelu(x)) + b1)) + b2; built for 32 and 64 channels (conv_pair_supported)
+bool conv_pair_supported(int C, int k, int dil);
+int32_t launch_conv_pair(asrfe_ctx* ctx, const float* x, float* out, const VocConv& c1, const VocConv& c2, int B, int T, float slope,
+                         hipStream_t s);
 int32_t prepare_conv(asrfe_ctx* ctx);  // per-device kernel attributes; called by asrfe_load_vocoder_weights
 // mel f32 [B][n_mels][T] -> 16-bit [B][T][n_mels]
 int32_t launch_mel_to_ntc(asrfe_ctx* ctx, const float* mel, int B, int n_mels, int T, uint16_t* out, hipStream_t s);

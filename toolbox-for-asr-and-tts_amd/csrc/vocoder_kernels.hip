@@ -241,6 +241,213 @@ __global__ __launch_bounds__(256, OCC) void conv_tile_kernel(const ConvParams p)
 #endif
 }
 
+// Residual pair of a block with few channels (32 or 64), fused: out = x + conv2(lrelu(conv1(lrelu(x)) + b1)) + b2 with
+// conv1 dilated and conv2 plain, both C -> C over k taps.  Below 128 channels a convolution is bound by its activation
+// traffic; run as two launches a pair moves 16 bytes per element (16-bit copy in, 16-bit intermediate out and in again,
+// f32 residual in, f32 and 16-bit results out), fused it moves 8: the f32 stream is read once (converted to the 16-bit
+// operand type, leaky ReLU applied, while it is staged) and written once; the intermediate never leaves the LDS.
+//   A workgroup (4 waves) owns M = 4 * NP * 32 positions of conv1's output, of which the inner P = M - (k - 1) are the
+//   positions of conv2's output it stores (conv2 needs (k - 1) / 2 rows of conv1 on either side; neighbouring tiles
+//   recompute those).  A1 = lrelu(x) rows [p0 - h2 - h1, ... + M + (k - 1) d), A2 = lrelu(conv1 + b1) rows
+//   [p0 - h2, ... + M) and zero outside the signal, both 16-bit in LDS with padded rows.  The weights of both
+//   convolutions stream through one LDS ring as one sequence of groups, so conv2's first groups arrive while conv1 ends.
+//   The arithmetic (operand rounding, accumulation order) is that of the two separate launches: results are identical.
+struct PairParams {
+    const float* x;       // [B][T][C] residual stream in
+    float* out;           // [B][T][C] residual stream out (a different buffer: tiles read their neighbours' rows of x)
+    const uint16_t* w1;   // [C][k * C]
+    const float* b1;
+    const uint16_t* w2;
+    const float* b2;
+    int T, k, dil;
+    float slope;
+};
+
+template <bool F16, int NC, int NP>
+__global__ __launch_bounds__(256, 2) void conv_pair_kernel(const PairParams p) {
+    extern __shared__ __attribute__((aligned(16))) char xs[];
+    saturate_fp16_conversions<F16>();
+    constexpr int C = NC * 32, M = 4 * NP * 32;
+    constexpr int NSLOT = kConvRingSlots, GS = 4;
+    constexpr int kRowBytes = 32 * GS, kSlotBytes = C * kRowBytes, kCpr = 2 * GS, kRowsPerInstr = 64 / kCpr;
+    constexpr int kInstrPerWave = C / kRowsPerInstr / 4;
+    constexpr int nblk = C / 16, cpr = C / 8, stride = 2 * C + 16;
+    constexpr int NSTG = 6;  // 32-byte pieces of the f32 stream a thread keeps in flight while staging
+    static_assert(kInstrPerWave >= 1, "ring geometry");
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, h = lane >> 5;
+    const int b = blockIdx.z;
+    const int h2 = (p.k - 1) / 2, h1 = h2 * p.dil;
+    const int P = M - 2 * h2;
+    const int p0 = blockIdx.x * P;
+    const int R1 = M + 2 * h1, R2 = M + 2 * h2;
+    const int K = p.k * C, S = p.k * nblk, G = (S + GS - 1) / GS;
+    const int a2_at = R1 * stride, zero_at = a2_at + R2 * stride;
+    const int ring_at = (zero_at + 16 + 127) & ~127;
+    const uint32_t ring_lds = __builtin_amdgcn_readfirstlane(lds_addr_of(xs) + ring_at);
+
+    // ---- conv2's accumulators start from the residual x (rows at or past min(T, p0 + P) read as 0 and are never stored:
+    // the buffer descriptors end there).  Requested first: they are the oldest loads when the first group is waited for.
+    f32x16 acc1[NC][NP], acc2[NC][NP];
+    const int n_rows = max(0, min(p.T, p0 + P));
+    const int64_t item = static_cast<int64_t>(b) * p.T * C;
+    constexpr uint32_t row4 = C * 4u;
+    const uint32_t lane_off4 = static_cast<uint32_t>(p0 + wave * (NP * 32) + 4 * h) * row4 + static_cast<uint32_t>(l31) * 4u;
+    auto off4 = [&](int nc, int np, int r) { return lane_off4 + static_cast<uint32_t>(np * 32 + 8 * (r >> 2) + (r & 3)) * row4 + nc * 128; };
+    {
+        const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x) + item, 0, n_rows * C * 4, 0x00020000);
+#pragma unroll
+        for (int nc = 0; nc < NC; ++nc)
+#pragma unroll
+            for (int np = 0; np < NP; ++np)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    acc2[nc][np][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(x_rsrc, off4(nc, np, r), 0, 0));
+                    acc1[nc][np][r] = 0.0f;
+                }
+    }
+
+    // ---- weight ring: groups 0 .. G - 1 are conv1's, G .. 2 G - 1 conv2's
+    const int srow = kRowsPerInstr * wave + lane / kCpr;
+    const int schunk = (lane & (kCpr - 1)) ^ ((srow >> 1) & (kCpr - 1));
+    const int wsw = (l31 >> 1) & (kCpr - 1);
+    int gi = 0;
+    auto issue = [&](int slot) {
+        const bool second = gi >= G;
+        const uint16_t* wt = second ? p.w2 : p.w1;
+        const int kofs = (second ? gi - G : gi) * (16 * GS);
+        const int ce = min(kofs + 8 * schunk, K - 8);  // (the last group may reach past the last k: those steps meet zeros)
+        const uint32_t dst = __builtin_amdgcn_readfirstlane(ring_lds + slot * kSlotBytes + wave * 1024);
+#pragma unroll
+        for (int i = 0; i < kInstrPerWave; ++i)
+            lds_dma16(wt, static_cast<uint32_t>((srow + 4 * kRowsPerInstr * i) * K + ce) * 2u, dst + i * 4096);
+        gi = min(gi + 1, 2 * G - 1);  // (issues past the end re-read the last group)
+    };
+#pragma unroll
+    for (int i = 0; i < NSLOT - 1; ++i) issue(i);
+
+    // ---- stage A1 = lrelu(x) rows [p0 - h2 - h1, + R1) as 16-bit, zero outside [0, T); clear A2's rows past M
+    {
+        const float* xitem = p.x + item;
+        const int first = p0 - h2 - h1;
+        const int n_chunks = R1 * cpr;
+        for (int i0 = tid; i0 < n_chunks; i0 += NSTG * 256) {
+            float4 va[NSTG], vb[NSTG];
+            int dst[NSTG];
+#pragma unroll
+            for (int u = 0; u < NSTG; ++u) {
+                const int i = i0 + u * 256;
+                const int r = i / cpr, c = i - r * cpr;
+                const int ti = first + r;
+                dst[u] = i < n_chunks ? r * stride + c * 16 : -1;
+                va[u] = vb[u] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                if (i < n_chunks && ti >= 0 && ti < p.T) {
+                    const float4* src = reinterpret_cast<const float4*>(xitem + static_cast<int64_t>(ti) * C + 8 * c);
+                    va[u] = src[0];
+                    vb[u] = src[1];
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < NSTG; ++u)
+                if (dst[u] >= 0)
+                    *reinterpret_cast<uint4*>(xs + dst[u]) =
+                        make_uint4(pack_elem2<F16>(lrelu(va[u].x, p.slope), lrelu(va[u].y, p.slope)),
+                                   pack_elem2<F16>(lrelu(va[u].z, p.slope), lrelu(va[u].w, p.slope)),
+                                   pack_elem2<F16>(lrelu(vb[u].x, p.slope), lrelu(vb[u].y, p.slope)),
+                                   pack_elem2<F16>(lrelu(vb[u].z, p.slope), lrelu(vb[u].w, p.slope)));
+        }
+        for (int i = tid; i < 2 * h2 * cpr; i += 256) {
+            const int r = M + i / cpr, c = i % cpr;
+            *reinterpret_cast<uint4*>(xs + a2_at + r * stride + c * 16) = make_uint4(0, 0, 0, 0);
+        }
+        if (tid == 0) *reinterpret_cast<uint4*>(xs + zero_at) = make_uint4(0, 0, 0, 0);
+    }
+    __syncthreads();
+
+    // ---- one convolution's k-steps: activations from rows (row of the lane's position) + tap * dtap of the region at
+    // `base`, weights from the ring; a step past the last one multiplies by the zero chunk
+    int slot = 0;
+    auto run = [&](int base, int dtap, f32x16 (&acc)[NC][NP]) {
+        const int xbase = base + (wave * (NP * 32) + l31) * stride + h * 16;
+        int tap = 0, cb = 0;
+        auto read_x = [&](u16x8 (&dst)[NP]) {
+            const bool real = tap < p.k;
+            const int at = real ? xbase + tap * dtap * stride + cb * 32 : zero_at;
+            const int step = real ? 32 * stride : 0;
+#pragma unroll
+            for (int np = 0; np < NP; ++np) dst[np] = *reinterpret_cast<const u16x8*>(xs + at + np * step);
+            if (++cb == nblk) { cb = 0; ++tap; }
+        };
+        auto read_w = [&](u16x8 (&dst)[NC], int sl, int j) {
+            const char* wp = xs + ring_at + sl * kSlotBytes + l31 * kRowBytes + (((2 * j + h) ^ wsw) << 4);
+#pragma unroll
+            for (int nc = 0; nc < NC; ++nc) dst[nc] = *reinterpret_cast<const u16x8*>(wp + nc * 32 * kRowBytes);
+        };
+        u16x8 xf[2][NP], wf[2][NC];
+        read_x(xf[0]);
+        for (int g = 0; g < G; ++g) {
+            // this wave's part of the group has landed (the younger groups may still fly), then all waves meet: the group
+            // is complete and nobody reads the one before it any more, whose slot takes the group NSLOT - 1 ahead
+            asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"((NSLOT - 2) * kInstrPerWave) : "memory");
+            issue(slot == 0 ? NSLOT - 1 : slot - 1);
+            read_w(wf[0], slot, 0);
+#pragma unroll
+            for (int j = 0; j < GS; ++j) {
+                read_x(xf[(j + 1) & 1]);
+                if (j + 1 < GS) read_w(wf[(j + 1) & 1], slot, j + 1);
+                __builtin_amdgcn_sched_barrier(0);  // the next step's fragment reads stay ahead of this step's MFMAs
+#pragma unroll
+                for (int nc = 0; nc < NC; ++nc)
+#pragma unroll
+                    for (int np = 0; np < NP; ++np) acc[nc][np] = mfma32<F16>(xf[j & 1][np], wf[j & 1][nc], acc[nc][np]);
+            }
+            slot = slot + 1 == NSLOT ? 0 : slot + 1;
+        }
+    };
+
+    run(0, p.dil, acc1);
+
+    // ---- A2 = lrelu(conv1 + b1) as 16-bit, zero where the position lies outside the signal (conv2's padding)
+    {
+        float bv[NC];
+#pragma unroll
+        for (int nc = 0; nc < NC; ++nc) bv[nc] = p.b1[nc * 32 + l31];
+#pragma unroll
+        for (int np = 0; np < NP; ++np)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int ql = wave * (NP * 32) + np * 32 + 8 * (r >> 2) + 4 * h + (r & 3);
+                const int q = p0 - h2 + ql;
+                const bool inside = q >= 0 && q < p.T;
+#pragma unroll
+                for (int nc = 0; nc < NC; ++nc) {
+                    const uint16_t v = inside ? to_elem<F16>(lrelu(acc1[nc][np][r] + bv[nc], p.slope)) : uint16_t{0};
+                    *reinterpret_cast<uint16_t*>(xs + a2_at + ql * stride + (nc * 32 + l31) * 2) = v;
+                }
+            }
+    }
+    __syncthreads();
+
+    run(a2_at, 1, acc2);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the ring's last (unused) groups
+
+    // ---- epilogue: bias, f32 rows out (32 lanes = the 32 consecutive channels of one position)
+    {
+        const __amdgpu_buffer_rsrc_t o_rsrc = __builtin_amdgcn_make_buffer_rsrc(p.out + item, 0, n_rows * C * 4, 0x00020000);
+        float bv[NC];
+#pragma unroll
+        for (int nc = 0; nc < NC; ++nc) bv[nc] = p.b2[nc * 32 + l31];
+#pragma unroll
+        for (int np = 0; np < NP; ++np)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+#pragma unroll
+                for (int nc = 0; nc < NC; ++nc)
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, acc2[nc][np][r] + bv[nc]), o_rsrc, off4(nc, np, r), 0, 0);
+    }
+}
+
 template <bool F16>
 __global__ __launch_bounds__(256) void mel_to_ntc_kernel(const float* __restrict__ mel, int n_mels, int T, uint16_t* __restrict__ out) {
     saturate_fp16_conversions<F16>();
@@ -340,6 +547,11 @@ int32_t prepare_conv(asrfe_ctx* ctx) {
                 if (!fn || hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, kConvLdsMax / occ) != hipSuccess)
                     return set_err(ctx, ASRFE_ERR_HIP, "vocoder convolution: cannot raise the dynamic LDS limit");
             }
+    const void* pair_fns[4] = {reinterpret_cast<const void*>(conv_pair_kernel<true, 2, 1>), reinterpret_cast<const void*>(conv_pair_kernel<false, 2, 1>),
+                               reinterpret_cast<const void*>(conv_pair_kernel<true, 1, 2>), reinterpret_cast<const void*>(conv_pair_kernel<false, 1, 2>)};
+    for (const void* fn : pair_fns)
+        if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, kConvLdsMax / 2) != hipSuccess)
+            return set_err(ctx, ASRFE_ERR_HIP, "vocoder pair: cannot raise the dynamic LDS limit");
     return ASRFE_OK;
 }
 
@@ -387,6 +599,48 @@ int32_t launch_conv_mfma(asrfe_ctx* ctx, const ConvParams& pin, hipStream_t s) {
     void* args[1] = {&p};
     if (hipLaunchKernel(fn, grid, block, args, lds, s) != hipSuccess) { /* reported below */ }
     VOC_CHECK_LAUNCH("vocoder convolution");
+    return ASRFE_OK;
+}
+
+namespace {
+template <int NC, int NP>
+int64_t pair_lds_bytes(int k, int dil) {
+    constexpr int C = NC * 32, M = 4 * NP * 32, stride = 2 * C + 16;
+    const int h2 = (k - 1) / 2;
+    const int64_t rows = (M + 2 * h2 * dil) + (M + 2 * h2);
+    return ((rows * stride + 16 + 127) & ~int64_t{127}) + kConvRingSlots * C * 128;
+}
+}  // namespace
+
+bool conv_pair_supported(int C, int k, int dil) {
+    if (k < 1 || k % 2 == 0 || dil < 1) return false;
+    if (C == 64) return k <= 33 && pair_lds_bytes<2, 1>(k, dil) <= kConvLdsMax / 2;
+    if (C == 32) return k <= 65 && pair_lds_bytes<1, 2>(k, dil) <= kConvLdsMax / 2;
+    return false;
+}
+
+int32_t launch_conv_pair(asrfe_ctx* ctx, const float* x, float* out, const VocConv& c1, const VocConv& c2, int B, int T, float slope,
+                         hipStream_t s) {
+    if (B <= 0 || T <= 0) return ASRFE_OK;
+    const int C = c1.Co;
+    if (c1.Ci != C || c2.Ci != C || c2.Co != C || c2.k != c1.k || c2.dil != 1 || !conv_pair_supported(C, c1.k, c1.dil) || x == out)
+        return set_err(ctx, ASRFE_ERR_SHAPE, "vocoder pair: not a residual pair this kernel is built for");
+    if (static_cast<int64_t>(T + 512) * C * 4 >= (int64_t{1} << 31) || B > 65535)
+        return set_err(ctx, ASRFE_ERR_SHAPE, "vocoder pair: one item's rows must stay below 2 GiB, batch below 65536");
+    PairParams p{};
+    p.x = x; p.out = out; p.w1 = c1.w; p.b1 = c1.bias; p.w2 = c2.w; p.b2 = c2.bias; p.T = T; p.k = c1.k; p.dil = c1.dil; p.slope = slope;
+    const bool f16 = ctx->cfg.enc_compute_dtype == ASRFE_DT_F16;
+    const int M = C == 64 ? 128 : 256, P = M - (c1.k - 1);
+    const unsigned lds = static_cast<unsigned>(C == 64 ? pair_lds_bytes<2, 1>(c1.k, c1.dil) : pair_lds_bytes<1, 2>(c1.k, c1.dil));
+    const dim3 grid((T + P - 1) / P, 1, B), block(256);
+    if (C == 64) {
+        if (f16) hipLaunchKernelGGL((conv_pair_kernel<true, 2, 1>), grid, block, lds, s, p);
+        else hipLaunchKernelGGL((conv_pair_kernel<false, 2, 1>), grid, block, lds, s, p);
+    } else {
+        if (f16) hipLaunchKernelGGL((conv_pair_kernel<true, 1, 2>), grid, block, lds, s, p);
+        else hipLaunchKernelGGL((conv_pair_kernel<false, 1, 2>), grid, block, lds, s, p);
+    }
+    VOC_CHECK_LAUNCH("vocoder pair");
     return ASRFE_OK;
 }
 
