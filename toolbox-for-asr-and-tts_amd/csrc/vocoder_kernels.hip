@@ -249,8 +249,12 @@ __global__ __launch_bounds__(256, OCC) void conv_tile_kernel(const ConvParams p)
 //   A workgroup (4 waves) owns M = 4 * NP * 32 positions of conv1's output, of which the inner P = M - (k - 1) are the
 //   positions of conv2's output it stores (conv2 needs (k - 1) / 2 rows of conv1 on either side; neighbouring tiles
 //   recompute those).  A1 = lrelu(x) rows [p0 - h2 - h1, ... + M + (k - 1) d), A2 = lrelu(conv1 + b1) rows
-//   [p0 - h2, ... + M) and zero outside the signal, both 16-bit in LDS with padded rows.  The weights of both
-//   convolutions stream through one LDS ring as one sequence of groups, so conv2's first groups arrive while conv1 ends.
+//   [p0 - h2, ... + M) and zero outside the signal, both 16-bit in LDS with padded rows; A2 takes A1's place once conv1
+//   has read it.  The weights of both convolutions stream through one LDS ring as one sequence of groups, so conv2's
+//   first groups arrive while conv1 ends.  A wave owns NC x NP accumulator tiles per convolution.  64 channels: 2 x 2
+//   (a k-step reads 4 fragments for 4 MFMAs; with 2 x 1 it reads 3 for 2 and the LDS, not the matrix pipe, sets the pace),
+//   two workgroups per CU.  32 channels: 1 x 2 and four workgroups per CU: there the pair is bound by its memory traffic
+//   and more workgroups in different phases hide more of it (measured against 1 x 4 with two per CU).
 //   The arithmetic (operand rounding, accumulation order) is that of the two separate launches: results are identical.
 struct PairParams {
     const float* x;       // [B][T][C] residual stream in
@@ -263,8 +267,8 @@ struct PairParams {
     float slope;
 };
 
-template <bool F16, int NC, int NP>
-__global__ __launch_bounds__(256, 2) void conv_pair_kernel(const PairParams p) {
+template <bool F16, int NC, int NP, int OCC>
+__global__ __launch_bounds__(256, OCC) void conv_pair_kernel(const PairParams p) {
     extern __shared__ __attribute__((aligned(16))) char xs[];
     saturate_fp16_conversions<F16>();
     constexpr int C = NC * 32, M = 4 * NP * 32;
@@ -283,7 +287,7 @@ __global__ __launch_bounds__(256, 2) void conv_pair_kernel(const PairParams p) {
     const int p0 = blockIdx.x * P;
     const int R1 = M + 2 * h1, R2 = M + 2 * h2;
     const int K = p.k * C, S = p.k * nblk, G = (S + GS - 1) / GS;
-    const int a2_at = R1 * stride, zero_at = a2_at + R2 * stride;
+    const int a2_at = 0, zero_at = max(R1, R2) * stride;  // A2 takes A1's rows once conv1 is done with them
     const int ring_at = (zero_at + 16 + 127) & ~127;
     const uint32_t ring_lds = __builtin_amdgcn_readfirstlane(lds_addr_of(xs) + ring_at);
 
@@ -327,7 +331,7 @@ __global__ __launch_bounds__(256, 2) void conv_pair_kernel(const PairParams p) {
 #pragma unroll
     for (int i = 0; i < NSLOT - 1; ++i) issue(i);
 
-    // ---- stage A1 = lrelu(x) rows [p0 - h2 - h1, + R1) as 16-bit, zero outside [0, T); clear A2's rows past M
+    // ---- stage A1 = lrelu(x) rows [p0 - h2 - h1, + R1) as 16-bit, zero outside [0, T)
     {
         const float* xitem = p.x + item;
         const int first = p0 - h2 - h1;
@@ -356,10 +360,6 @@ __global__ __launch_bounds__(256, 2) void conv_pair_kernel(const PairParams p) {
                                    pack_elem2<F16>(lrelu(va[u].z, p.slope), lrelu(va[u].w, p.slope)),
                                    pack_elem2<F16>(lrelu(vb[u].x, p.slope), lrelu(vb[u].y, p.slope)),
                                    pack_elem2<F16>(lrelu(vb[u].z, p.slope), lrelu(vb[u].w, p.slope)));
-        }
-        for (int i = tid; i < 2 * h2 * cpr; i += 256) {
-            const int r = M + i / cpr, c = i % cpr;
-            *reinterpret_cast<uint4*>(xs + a2_at + r * stride + c * 16) = make_uint4(0, 0, 0, 0);
         }
         if (tid == 0) *reinterpret_cast<uint4*>(xs + zero_at) = make_uint4(0, 0, 0, 0);
     }
@@ -408,8 +408,14 @@ __global__ __launch_bounds__(256, 2) void conv_pair_kernel(const PairParams p) {
 
     run(0, p.dil, acc1);
 
-    // ---- A2 = lrelu(conv1 + b1) as 16-bit, zero where the position lies outside the signal (conv2's padding)
+    // ---- A2 = lrelu(conv1 + b1) as 16-bit, zero where the position lies outside the signal (conv2's padding); its rows
+    // past M (read by the taps of positions that are not stored) are cleared.  Every wave is done reading A1 first.
+    __syncthreads();
     {
+        for (int i = tid; i < 2 * h2 * cpr; i += 256) {
+            const int r = M + i / cpr, c = i % cpr;
+            *reinterpret_cast<uint4*>(xs + a2_at + r * stride + c * 16) = make_uint4(0, 0, 0, 0);
+        }
         float bv[NC];
 #pragma unroll
         for (int nc = 0; nc < NC; ++nc) bv[nc] = p.b1[nc * 32 + l31];
@@ -547,8 +553,8 @@ int32_t prepare_conv(asrfe_ctx* ctx) {
                 if (!fn || hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, kConvLdsMax / occ) != hipSuccess)
                     return set_err(ctx, ASRFE_ERR_HIP, "vocoder convolution: cannot raise the dynamic LDS limit");
             }
-    const void* pair_fns[4] = {reinterpret_cast<const void*>(conv_pair_kernel<true, 2, 1>), reinterpret_cast<const void*>(conv_pair_kernel<false, 2, 1>),
-                               reinterpret_cast<const void*>(conv_pair_kernel<true, 1, 2>), reinterpret_cast<const void*>(conv_pair_kernel<false, 1, 2>)};
+    const void* pair_fns[4] = {reinterpret_cast<const void*>(conv_pair_kernel<true, 2, 2, 2>), reinterpret_cast<const void*>(conv_pair_kernel<false, 2, 2, 2>),
+                               reinterpret_cast<const void*>(conv_pair_kernel<true, 1, 2, 4>), reinterpret_cast<const void*>(conv_pair_kernel<false, 1, 2, 4>)};
     for (const void* fn : pair_fns)
         if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, kConvLdsMax / 2) != hipSuccess)
             return set_err(ctx, ASRFE_ERR_HIP, "vocoder pair: cannot raise the dynamic LDS limit");
@@ -607,15 +613,15 @@ template <int NC, int NP>
 int64_t pair_lds_bytes(int k, int dil) {
     constexpr int C = NC * 32, M = 4 * NP * 32, stride = 2 * C + 16;
     const int h2 = (k - 1) / 2;
-    const int64_t rows = (M + 2 * h2 * dil) + (M + 2 * h2);
+    const int64_t rows = M + 2 * h2 * std::max(dil, 1);  // A1; A2 (M + 2 h2 rows) takes its place
     return ((rows * stride + 16 + 127) & ~int64_t{127}) + kConvRingSlots * C * 128;
 }
 }  // namespace
 
 bool conv_pair_supported(int C, int k, int dil) {
     if (k < 1 || k % 2 == 0 || dil < 1) return false;
-    if (C == 64) return k <= 33 && pair_lds_bytes<2, 1>(k, dil) <= kConvLdsMax / 2;
-    if (C == 32) return k <= 65 && pair_lds_bytes<1, 2>(k, dil) <= kConvLdsMax / 2;
+    if (C == 64) return k <= 33 && pair_lds_bytes<2, 2>(k, dil) <= kConvLdsMax / 2;
+    if (C == 32) return k <= 65 && pair_lds_bytes<1, 2>(k, dil) <= kConvLdsMax / 4;
     return false;
 }
 
@@ -625,20 +631,20 @@ int32_t launch_conv_pair(asrfe_ctx* ctx, const float* x, float* out, const VocCo
     const int C = c1.Co;
     if (c1.Ci != C || c2.Ci != C || c2.Co != C || c2.k != c1.k || c2.dil != 1 || !conv_pair_supported(C, c1.k, c1.dil) || x == out)
         return set_err(ctx, ASRFE_ERR_SHAPE, "vocoder pair: not a residual pair this kernel is built for");
-    if (static_cast<int64_t>(T + 512) * C * 4 >= (int64_t{1} << 31) || B > 65535)
+    if (static_cast<int64_t>(T + 1024) * C * 4 >= (int64_t{1} << 31) || B > 65535)
         return set_err(ctx, ASRFE_ERR_SHAPE, "vocoder pair: one item's rows must stay below 2 GiB, batch below 65536");
     PairParams p{};
     p.x = x; p.out = out; p.w1 = c1.w; p.b1 = c1.bias; p.w2 = c2.w; p.b2 = c2.bias; p.T = T; p.k = c1.k; p.dil = c1.dil; p.slope = slope;
     const bool f16 = ctx->cfg.enc_compute_dtype == ASRFE_DT_F16;
-    const int M = C == 64 ? 128 : 256, P = M - (c1.k - 1);
-    const unsigned lds = static_cast<unsigned>(C == 64 ? pair_lds_bytes<2, 1>(c1.k, c1.dil) : pair_lds_bytes<1, 2>(c1.k, c1.dil));
+    const int M = 256, P = M - (c1.k - 1);
+    const unsigned lds = static_cast<unsigned>(C == 64 ? pair_lds_bytes<2, 2>(c1.k, c1.dil) : pair_lds_bytes<1, 2>(c1.k, c1.dil));
     const dim3 grid((T + P - 1) / P, 1, B), block(256);
     if (C == 64) {
-        if (f16) hipLaunchKernelGGL((conv_pair_kernel<true, 2, 1>), grid, block, lds, s, p);
-        else hipLaunchKernelGGL((conv_pair_kernel<false, 2, 1>), grid, block, lds, s, p);
+        if (f16) hipLaunchKernelGGL((conv_pair_kernel<true, 2, 2, 2>), grid, block, lds, s, p);
+        else hipLaunchKernelGGL((conv_pair_kernel<false, 2, 2, 2>), grid, block, lds, s, p);
     } else {
-        if (f16) hipLaunchKernelGGL((conv_pair_kernel<true, 1, 2>), grid, block, lds, s, p);
-        else hipLaunchKernelGGL((conv_pair_kernel<false, 1, 2>), grid, block, lds, s, p);
+        if (f16) hipLaunchKernelGGL((conv_pair_kernel<true, 1, 2, 4>), grid, block, lds, s, p);
+        else hipLaunchKernelGGL((conv_pair_kernel<false, 1, 2, 4>), grid, block, lds, s, p);
     }
     VOC_CHECK_LAUNCH("vocoder pair");
     return ASRFE_OK;
