@@ -98,6 +98,15 @@ def test_fused_pairs_equal_the_two_launch_form(pkg, cfg, t_mel, monkeypatch):
     assert torch.equal(one, two)
 
 
+@pytest.mark.parametrize("t_mel", [1, 2, 3])
+def test_generator_shortest_inputs(pkg, t_mel):
+    """One to three mel frames: every stage is shorter than a position tile and, in the fused stages, than the taps' reach."""
+    cfg = ho.HifiganConfig()
+    gen, sd = build(cfg, seed=23)
+    mel = torch.randn(2, cfg.n_mels, t_mel, generator=torch.Generator().manual_seed(100 + t_mel))
+    check(gen, sd, cfg, mel)
+
+
 def test_generator_fixture(pkg):
     import os
     g = np.load(os.path.join(os.path.dirname(__file__), "golden", "vocoder_tiny.npz"))
