@@ -156,17 +156,19 @@ def cpu_baseline(sd, n_clips: int, batch: int = 8):
         cxx = cxx_cpu_baseline(sd, nthr)
     except Exception as e:  # (the C++ restatement is a second opinion: its absence must not cost the bench line)
         cxx = {"error": f"{type(e).__name__}: {e}"}
+    finally:
+        torch.set_num_threads(nthr)  # (the restatement's one-thread leg sets the OpenMP thread count torch shares)
     return {
         "cxx_port": cxx,
         "value": n_clips / (t_front + t_enc),
         "one_thread_value": 1.0 / t_one,
         "unit": "utt/s",
-        "cores": int(torch.get_num_threads()),
+        "cores": int(nthr),
         "host_cpus": os.cpu_count(),
         "cpu_model": cpu_model(),
         "kind": "port",
         "sample": f"{n_clips} x 30 s utterances ({batch} per call) through oracle/fbank_oracle.py (numpy f64, 1 thread) "
-                  f"and oracle/sanm_oracle.py (torch fp32, {torch.get_num_threads()} threads), 50 blocks",
+                  f"and oracle/sanm_oracle.py (torch fp32, {nthr} threads), 50 blocks",
         "frontend_s": t_front,
         "encoder_s": t_enc,
     }

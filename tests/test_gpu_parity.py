@@ -439,10 +439,27 @@ def test_post_attention_kernel_vs_fp64(pkg):
         qref = n1 @ w["encoders.0.self_attn.linear_q_k_v.weight"].T + w["encoders.0.self_attn.linear_q_k_v.bias"]
         assert torch.equal(xo, xo2), (m, with_x)
         assert float((qkv.double() - qref).abs().max()) <= 2e-2, (m, with_x)
+        # the residual stream in the kernel's register order (flags bit 9; what the encoder's throughput plan passes
+        # from layer to layer): the same numbers bit for bit, whole 128-row tiles per buffer
+        mp = (m + 127) // 128 * 128
+        xt = torch.zeros(mp, 512, device="cuda")
+        xt[:m] = x
+        xt = xt.view(mp // 32, 32, 16, 4, 2, 4).permute(0, 2, 3, 4, 1, 5).contiguous()
+        xo3 = torch.empty_like(x)  # tiled in, row-major out: the encoder's last layer
+        ctx.check(ctx.lib.asrfe_debug_post_attn(ctx.handle, 0, att.data_ptr(), fsmn.data_ptr(),
+                                                xt.data_ptr() if with_x else None, xo3.data_ptr(), None, None, m, 512, stream))
+        assert torch.equal(xo, xo3), (m, with_x)
+        xo4 = torch.full((mp // 32, 16, 4, 2, 32, 4), float("nan"), device="cuda")  # tiled in and out, with q, k, v
+        qkv4 = torch.empty_like(qkv)
+        ctx.check(ctx.lib.asrfe_debug_post_attn(ctx.handle, 0, att.data_ptr(), fsmn.data_ptr(),
+                                                xt.data_ptr() if with_x else None, xo4.data_ptr(), None, qkv4.data_ptr(), m, 512,
+                                                stream))
+        assert torch.equal(xo, xo4.permute(0, 4, 1, 2, 3, 5).reshape(mp, 512)[:m]), (m, with_x)
+        assert torch.equal(qkv, qkv4), (m, with_x)
 
 
 def test_fused_and_unfused_encoder_paths_agree(pkg, monkeypatch):
-    """Four launch plans for the same layers: the throughput plan (the post-attention kernel also projects the next
+    """Launch plans for the same layers: the throughput plan (the post-attention kernel also projects the next
     layer's q, k, v), ASRFE_SEPARATE_QKV=1 (it writes the normalised rows and every layer launches its own projection),
     ASRFE_UNFUSED_FFN=1 (separate LayerNorm / GEMM launches) and the latency plan (32 x 32 output tiles, the default
     at this size).  Each must meet the parity bar; they round to 16 bits at different points, so among themselves they
@@ -452,9 +469,11 @@ def test_fused_and_unfused_encoder_paths_agree(pkg, monkeypatch):
     lens = torch.tensor([130, 77], dtype=torch.int32)
     feats = so.synth_feats(2, 130, 560, seed=8)
     outs = []
-    for unfused, separate, small in (("0", "0", 0), ("0", "1", 0), ("1", "0", 0), ("0", "0", 1024)):
+    for unfused, separate, small, rowx in (("0", "0", 0, "0"), ("0", "1", 0, "0"), ("1", "0", 0, "0"), ("0", "0", 1024, "0"),
+                                           ("0", "0", 0, "1")):
         monkeypatch.setenv("ASRFE_UNFUSED_FFN", unfused)
         monkeypatch.setenv("ASRFE_SEPARATE_QKV", separate)
+        monkeypatch.setenv("ASRFE_ROW_MAJOR_X", rowx)
         enc = pkg.SANMEncoder(num_blocks=3, small_batch_rows=small)
         enc.load_state_dict(sd)
         out, _, _ = enc.forward(feats.cuda(), lens)
@@ -466,6 +485,9 @@ def test_fused_and_unfused_encoder_paths_agree(pkg, monkeypatch):
     assert float((outs[0] - outs[2]).abs().max()) <= 4e-3
     assert float((outs[0] - outs[3]).abs().max()) <= 4e-3
     assert not torch.equal(outs[0], outs[3])  # the latency plan really is another sequence of kernels
+    # ASRFE_ROW_MAJOR_X=1 keeps the residual stream row-major between the post-attention launches (the throughput plan
+    # otherwise hands it on in the kernel's register order): the same arithmetic in the same order
+    assert torch.equal(outs[0], outs[4])
 
 
 def test_engine_streams_give_identical_results(pkg):

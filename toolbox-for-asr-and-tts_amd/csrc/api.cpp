@@ -171,6 +171,8 @@ extern "C" int32_t asrfe_create(const asrfe_config* cfg, asrfe_ctx** out) {
         ctx->unfused_ffn = e && e[0] == '1';
         e = std::getenv("ASRFE_SEPARATE_QKV");
         ctx->separate_qkv = e && e[0] == '1';
+        e = std::getenv("ASRFE_ROW_MAJOR_X");
+        ctx->row_major_x = e && e[0] == '1';
     }
     // the latency plan's second feed-forward product takes linear_units in 512-deep steps up to 3072
     ctx->small_rows = (cfg->enc_linear_units % 512 == 0 && cfg->enc_linear_units <= 3072 && !ctx->unfused_ffn) ? cfg->enc_small_batch_rows : 0;
@@ -377,16 +379,18 @@ extern "C" int32_t asrfe_load_cmvn(asrfe_ctx* ctx, const float* shift, const flo
 
 // ---- encoder weights ---------------------------------------------------------------------------
 // Wo [512][512], W1 [ff][512] and W2 [512][ff] as the piece stream of the fused post-attention kernel (16 KiB
-// LDS images in consumption order).  Four chunks of Wo come first: piece r of chunk c is
-// Wo[128 (r & 3) .. +128][64 (2 c + (r >> 2)) .. +64] as 128 rows of 128 bytes, 16-byte slot cs of row r holding
+// LDS images in consumption order).  Four chunks of Wo come first, one per quarter of the output columns (the kernel
+// finishes a quarter before it starts the next, so the residual tiles of the later quarters can arrive meanwhile):
+// piece r of chunk c is Wo[128 c .. +128][64 r .. +64] as 128 rows of 128 bytes, 16-byte slot cs of row r holding
 // source chunk cs ^ ((r >> 1) & 7).  Then, for every chunk j of 64 hidden units, four images of
 // W1[64 j .. +64][128 ks .. +128] (64 rows of 256 bytes, slot cs of row r holding source chunk cs ^ (r & 15))
 // followed by four images of W2[128 nq .. +128][64 j .. +64] (128-byte rows as for Wo).  Inside every group of 16
 // columns of W1 and W2 the k order is p -> swap of bits 2 and 3 of p, the order in which accumulator registers
 // feed the next MFMA; Wo keeps the natural order (its operand is loaded from memory).
 // With wqkv (the NEXT layer's folded [1536][512] projection) twelve more chunks follow, three passes of 512 output
-// rows laid out like Wo but in the swapped k order (their operand is fed from accumulator registers too), and one
-// chunk of zeros that the kernel's last pass prefetches without reading.
+// rows in images like Wo's but k-major (chunk c of a pass holds k-slices 2 c and 2 c + 1 of all four column quarters:
+// piece r is rows 128 (r & 3) .. +128, k-slice 2 c + (r >> 2)) and in the swapped k order (their operand is fed from
+// accumulator registers too), and one chunk of zeros that the kernel's last pass prefetches without reading.
 static int32_t up_layer_stream(asrfe_ctx* ctx, const HostTensor* wo, const HostTensor* w1, const HostTensor* w2,
                                const HostTensor* wqkv, uint16_t** dev) {
     const int64_t ff = w1->shape[0], d = w1->shape[1];
@@ -398,7 +402,7 @@ static int32_t up_layer_stream(asrfe_ctx* ctx, const HostTensor* wo, const HostT
     for (int64_t c = 0; c < 4; ++c)
         for (int64_t r8 = 0; r8 < 8; ++r8) {
             uint16_t* img = v.data() + (8 * c + r8) * 8192;
-            const int64_t ks = 2 * c + (r8 >> 2), nq = r8 & 3;
+            const int64_t ks = r8, nq = c;
             for (int64_t r = 0; r < 128; ++r)
                 for (int64_t cs = 0; cs < 8; ++cs)
                     for (int64_t e = 0; e < 8; ++e)
@@ -668,7 +672,8 @@ extern "C" int32_t asrfe_debug_post_attn(asrfe_ctx* ctx, int32_t layer, const vo
         if (!L.stream_has_qkv) return set_err(ctx, ASRFE_ERR_BAD_ARG, "asrfe_debug_post_attn: this layer's stream has no QKV weights");
         f.qkv = qkv; f.ldq = 1536; f.bqkv = ctx->layers[layer + 1].b_qkv;
     }
-    f.eps = ctx->cfg.enc_ln_eps; f.M = m; f.ff = ctx->cfg.enc_linear_units; f.flags = flags;
+    f.eps = ctx->cfg.enc_ln_eps; f.M = m; f.ff = ctx->cfg.enc_linear_units; f.flags = flags & ~512;
+    f.tiled = (flags & 512) ? 1 : 0;
     return launch_post_attn(ctx, f, static_cast<hipStream_t>(stream));
 }
 

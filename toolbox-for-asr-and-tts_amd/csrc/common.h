@@ -84,6 +84,7 @@ struct asrfe_ctx {
     int num_cus;  // compute units of the device (persistent kernels launch one workgroup per CU)
     bool unfused_ffn;  // ASRFE_UNFUSED_FFN=1 in the environment: LayerNorm + two GEMM launches instead of the fused kernel
     bool separate_qkv;  // ASRFE_SEPARATE_QKV=1: every layer launches its own QKV projection
+    bool row_major_x;   // ASRFE_ROW_MAJOR_X=1: the residual stream stays row-major between post-attention launches
     int small_rows;     // encoder calls of at most this many rows take the latency plan (0: never)
     std::vector<asrfe::LayerWeights> layers;
     float* after_g;

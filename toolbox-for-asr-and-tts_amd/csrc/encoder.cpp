@@ -6,6 +6,7 @@
 //     every layer:   att = softmax(q k^T / sqrt(128)) v,  fsmn = FSMN(v)     attention kernel   16-bit [M][512] each
 //                    x = att Wo^T + b + fsmn (+ x);  x += W2 relu(W1 n(x) + b1) + b2;  qkv of the NEXT layer
 //                                                             post-attention kernel   f32 [M][512], 16-bit [M][1536]
+//                    (x stays in that kernel's register order between its launches; the last layer writes it row-major)
 //     at the end:    out = after_norm(x), rows past lens zero  ln kernel
 // ASRFE_SEPARATE_QKV=1 / ASRFE_UNFUSED_FFN=1 (read in asrfe_create) select the plans with more launches per layer
 // (a projection launch per layer; LayerNorm + four GEMM launches).  The residual stream x stays fp32; MFMA operands
@@ -46,7 +47,7 @@ Buffers carve(const asrfe_ctx* ctx, void* ws, int B, int Tp) {
     const int64_t hk = ctx->kin_pad > 512 ? ctx->kin_pad : 512;
     Carve c{static_cast<char*>(ws)};
     Buffers b;
-    b.x = c.take<float>(M * 512);
+    b.x = c.take<float>((M + 127) / 128 * 128 * 512);  // whole 128-row tiles: see FfnParams::tiled
     b.h = c.take<uint16_t>(M * hk);
     b.qkv = c.take<uint16_t>(M * 1536);
     b.fsmn = c.take<uint16_t>(M * 512);
@@ -92,6 +93,11 @@ int32_t encoder_forward(asrfe_ctx* ctx, const float* feats, const int32_t* lens,
     };
 
     bool qkv_ready = false;  // the previous layer's post-attention kernel already projected this layer's q, k, v
+    // When every layer but the last hands q, k, v to the next one, the residual stream only ever passes from one
+    // post-attention launch to the next: it is then kept in that kernel's register order (FfnParams::tiled) and the
+    // last layer writes the row-major x that after_norm reads.
+    bool tiled = !small && !ctx->unfused_ffn && !ctx->separate_qkv && c.enc_num_blocks > 1 && !ctx->row_major_x;
+    for (int li = 0; tiled && li + 1 < c.enc_num_blocks; ++li) tiled = ctx->layers[li].stream_has_qkv;
     for (int li = 0; li < c.enc_num_blocks; ++li) {
         const LayerWeights& L = ctx->layers[li];
         const int kin = li == 0 ? ctx->kin_pad : 512;
@@ -150,7 +156,7 @@ int32_t encoder_forward(asrfe_ctx* ctx, const float* feats, const int32_t* lens,
             const bool with_qkv = has_next && L.stream_has_qkv && !ctx->separate_qkv;
             FfnParams f{};
             f.att = bf.att; f.fsmn = bf.fsmn;
-            f.x = li == 0 ? nullptr : bf.x; f.x_out = bf.x;
+            f.x = li == 0 ? nullptr : bf.x; f.x_out = bf.x; f.tiled = tiled;
             f.wstream = L.w_stream; f.bo = L.b_out; f.b1 = L.b_ffn1; f.b2 = L.b_ffn2;
             f.y = has_next && !with_qkv ? bf.h : nullptr; f.ldy = 512;
             if (with_qkv) {

@@ -30,7 +30,7 @@
 // chunk per 64 hidden units and, for OUT 2, by 12 chunks of the next layer's Wqkv (three passes of 512 output
 // columns, each laid out like Wo but with the k order of accumulator-fed operands) and one chunk of padding that
 // the last pass prefetches and nobody reads:
-//     Wo chunk c, piece r : Wo[128 (r & 3) .. +128][64 (2 c + (r >> 2)) .. +64]
+//     Wo chunk c, piece r : Wo[128 c .. +128][64 r .. +64]      (one chunk = one quarter of the output columns)
 //     FFN pieces 0..3     : W1[chunk rows 64][128 k]   (256-byte rows, 16-byte slot c of row r holds chunk c ^ (r & 15))
 //     FFN pieces 4..7     : W2[128 n][chunk cols 64]
 // (128-byte rows: slot c of row r holds chunk c ^ ((r >> 1) & 7)).  The host stores the stream of these images
@@ -106,6 +106,46 @@ __device__ __forceinline__ void tile_in(f32x16& acc, const f32x16 t) {
 }
 
 typedef float v2f __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// 16 bytes per lane from sbase + voff + OFF into registers.  Issued through inline assembly like the LDS-DMA loads:
+// the kernel counts vector-memory operations itself (they complete in issue order), and a load the compiler could
+// see would make it insert waits that know nothing of the DMA loads in flight behind it.  The destination holds
+// the data only after a wait that names it (wait_vm_regs / wait_vm_barrier_regs below).
+template <int OFF>
+__device__ __forceinline__ void gload16(f32x4& dst, const void* sbase, uint32_t voff) {
+    asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "=v"(dst) : "v"(voff), "s"(sbase), "n"(OFF) : "memory");
+}
+template <int N>
+__device__ __forceinline__ void wait_vm_regs(f32x4 (&r)[4]) {
+    asm volatile("s_waitcnt vmcnt(%4)" : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]) : "n"(N) : "memory");
+}
+template <int N>
+__device__ __forceinline__ void wait_vm_barrier_regs(f32x4 (&r)[4]) {
+    asm volatile("s_waitcnt vmcnt(%4)\n\ts_barrier" : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]) : "n"(N) : "memory");
+}
+
+// ---- vector-memory bookkeeping of the output projection when the residual stream arrives beside it (TILED) ----
+// Before the pass the wave has issued weight pieces 0..6; piece i of the pass issues piece i + 7 (four DMA loads, at
+// MFMAs 0, 2, 4, 6 of its second half) and, when i is even and at most 16, the four loads of residual tile 7 + i / 2
+// (at MFMAs 1, 3, 5, 7).  In the middle of piece i the wave needs piece i + 1 and, when i is even and at most 22,
+// residual tile 4 + i / 2 (loaded by piece i - 6, or before the pass).
+constexpr int xload_piece(int j) { return (j >= 0 && j <= 16 && j % 2 == 0) ? 1 : 0; }
+// operations younger than the last DMA load of piece i + 1 at that point
+constexpr int out_proj_vmcnt(int i) {
+    int n = 0;
+    if (i + 1 <= 6) {
+        n = 4 * (6 - (i + 1));
+        for (int j = 0; j < i; ++j) n += 4 + 4 * xload_piece(j);
+    } else {
+        n = xload_piece(i - 6);
+        for (int j = i - 5; j < i; ++j) n += 4 + 4 * xload_piece(j);
+    }
+    return n;
+}
+// ... and younger than the last load of the residual tile that piece i adds (that load is the last operation of
+// piece i - 6, one behind the DMA loads of piece i + 1)
+constexpr int out_proj_vmcnt_x(int i) { return i >= 6 ? out_proj_vmcnt(i) - 1 : out_proj_vmcnt(i); }
 
 // Row statistics of a lane's 256 values (16 tiles of 16): sums of (x - k) and (x - k)^2 with k = the mean of the
 // lane's first tile, two values per packed instruction (1.5 instructions per value).  The shift keeps the variance
@@ -160,7 +200,13 @@ __device__ __forceinline__ u16x8 pack8(float a0, float a1, float a2, float a3, f
 
 
 // OUT: 0 = x_out only, 1 = x_out and y, 2 = x_out and the next layer's qkv
-template <bool F16, int OUT>
+// TILED: the residual stream between two launches of this kernel is kept in the order the row tile has in registers
+// (block (32-row group, tile nt, quad g) = 64 lanes x 16 bytes: lane l31 + 32 h holds columns 32 nt + 8 g + 4 h .. + 3
+// of row l31), so a wave reads and writes it as whole 1 KiB runs straight from / into registers, with no trip through
+// LDS.  x is read in that order; x_out is written in it for OUT 2 and row-major otherwise (the encoder's last layer).
+// Only the tiles of the first column quarter are added before the output projection starts; the other twelve arrive
+// while it runs and are added to their (not yet started) quarter's tiles between its MFMAs.
+template <bool F16, int OUT, bool TILED>
 __global__ __launch_bounds__(kFfnThreads) void post_attn_kernel(const FfnParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     saturate_fp16_conversions<F16>();
@@ -229,13 +275,105 @@ __global__ __launch_bounds__(kFfnThreads) void post_attn_kernel(const FfnParams 
     //      Row tile layout: register 4 g + e of tile nt is column 32 nt + 8 g + 4 h + e of row l31.
     f32x16 oacc[16];
     u16x8 afrag[32];  // att, later n(x_mid), as operand fragments: fragment s covers k = 16 s .. 16 s + 15
-    {
+    const bool has_x = p.x != nullptr;  // layer 0 has no residual into the attention block: x counts as zero
+    // TILED: four register sets for residual tiles; tiles 0..3 use all four before the projection, tiles 4..15 rotate
+    // through sets 0..2 while it runs
+    f32x4 xr[4][4];
+    const uint32_t lane16 = lane * 16;
+    // the wave's 32-row group of the tiled residual stream (64 KiB); layer 0 reads (and ignores) the first 64 KiB of
+    // the weight stream instead, so that the count of loads in flight is the same in every layer
+    const char* xtile = has_x ? reinterpret_cast<const char*>(p.x) + static_cast<int64_t>(row0 >> 5) * 65536 : wsrc;
+    auto xload = [&](auto setc, int nt, auto gc) {
+        constexpr int S = decltype(setc)::value, G = decltype(gc)::value;
+        gload16<G * 1024>(xr[S][G], xtile + nt * 4096, lane16);
+    };
+    if constexpr (TILED) {
+        static_for<4>([&](auto sc) {
+            static_for<4>([&](auto gc) { xload(sc, decltype(sc)::value, gc); });
+        });
+    }
+    if constexpr (TILED) {
+        const uint32_t xs_lds = __builtin_amdgcn_readfirstlane(smem_base + (4 + wave) * kPieceBytes);
+        const char* xs = smem + (4 + wave) * kPieceBytes;
+        const int rbase = min(row0, p.M - 1);
+        const char* asrc = reinterpret_cast<const char*>(p.att) + static_cast<int64_t>(rbase) * 1024;
+        const char* fsrc = reinterpret_cast<const char*>(p.fsmn) + static_cast<int64_t>(rbase) * 1024;
+        uint32_t aoff[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int r = 8 * k + (lane >> 3);
+            const int rr = min(row0 + r, p.M - 1) - rbase;
+            aoff[k] = static_cast<uint32_t>(rr * 1024 + (((lane & 7) ^ (r & 7)) << 4));
+        }
+        // slabs 0..7: att k-slices, slabs 8..15: fsmn column pairs of tiles (2 p, 2 p + 1)
+        auto slab_dma = [&](auto ic) {
+            constexpr int I = decltype(ic)::value;
+            const uint32_t dst = xs_lds + (I & 3) * 4096;
+            const char* src = I < 8 ? asrc + I * 128 : fsrc + (I - 8) * 128;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) lds_dma16(src, aoff[k], dst + k * 1024);
+        };
+        slab_dma(IC<0>{}); slab_dma(IC<1>{}); slab_dma(IC<2>{}); slab_dma(IC<3>{});
+        uint2 fs[8];
+        static_for<16>([&](auto ic) {
+            constexpr int I = decltype(ic)::value;
+            // Loads in flight behind slab I: the three slabs after it, and from slab 10 on the twelve loads of
+            // residual tiles 4..6, which are issued between slabs 13 and 14.  The residual tiles 0..3 were requested
+            // before any slab, so they have arrived with the first one.
+            if constexpr (I <= 9) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+            else if constexpr (I <= 12) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+            else if constexpr (I == 13) asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
+            else if constexpr (I == 14) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const char* sl = xs + (I & 3) * 4096 + l31 * 128;
+            const int sw = l31 & 7;
+            if constexpr (I < 8) {
+#pragma unroll
+                for (int s = 0; s < 4; ++s)
+                    afrag[4 * I + s] = *reinterpret_cast<const u16x8*>(sl + (((2 * s + h) ^ sw) << 4));
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(afrag[4 * I]), "+v"(afrag[4 * I + 1]), "+v"(afrag[4 * I + 2]), "+v"(afrag[4 * I + 3]) : : "memory");
+            } else {
+                constexpr int P = I - 8;
+#pragma unroll
+                for (int q = 0; q < 8; ++q) fs[q] = *reinterpret_cast<const uint2*>(sl + ((q ^ sw) << 4) + 8 * h);
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fs[0]), "+v"(fs[1]), "+v"(fs[2]), "+v"(fs[3]), "+v"(fs[4]), "+v"(fs[5]), "+v"(fs[6]), "+v"(fs[7]) : : "memory");
+                static_for<2>([&](auto nsc) {
+                    constexpr int ns = decltype(nsc)::value, nt = 2 * P + ns;
+                    f32x16 t;
+                    if constexpr (nt < 4) wait_vm_regs<63>(xr[nt]);  // (arrived long ago: this only names the registers)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        float f0, f1, f2, f3;
+                        unpack_elem2<F16>(fs[4 * ns + g].x, f0, f1);
+                        unpack_elem2<F16>(fs[4 * ns + g].y, f2, f3);
+                        const float4 bo4 = *reinterpret_cast<const float4*>(bos + 32 * nt + 8 * g + 4 * h);
+                        t[4 * g] = f0 + bo4.x; t[4 * g + 1] = f1 + bo4.y; t[4 * g + 2] = f2 + bo4.z; t[4 * g + 3] = f3 + bo4.w;
+                        if constexpr (nt < 4) {
+                            if (has_x) {
+                                t[4 * g] += xr[nt][g][0]; t[4 * g + 1] += xr[nt][g][1];
+                                t[4 * g + 2] += xr[nt][g][2]; t[4 * g + 3] += xr[nt][g][3];
+                            }
+                        }
+                    }
+                    tile_in(oacc[nt], t);
+                });
+            }
+            if constexpr (I + 4 < 16) slab_dma(IC<I + 4>{});
+            if constexpr (I == 9) {
+                static_for<3>([&](auto sc) {
+                    static_for<4>([&](auto gc) { xload(sc, 4 + decltype(sc)::value, gc); });
+                });
+            }
+        });
+        // every wave is done with its slabs: slots 4..6 can take their weight pieces
+        __syncthreads();
+        stage(IC<4>{}, cb_first); stage(IC<5>{}, cb_first); stage(IC<6>{}, cb_first);
+    } else {
         const uint32_t xs_lds = __builtin_amdgcn_readfirstlane(smem_base + (4 + wave) * kPieceBytes);
         const char* xs = smem + (4 + wave) * kPieceBytes;
         // the per-lane offset is an UNSIGNED 32-bit addend of the scalar base, so the base is the wave's first valid
         // row and rows past M - 1 re-read row M - 1 (never a negative offset)
         const int rbase = min(row0, p.M - 1);
-        const bool has_x = p.x != nullptr;  // layer 0 has no residual into the attention block: x counts as zero
         const char* xsrc = reinterpret_cast<const char*>(has_x ? p.x : p.x_out) + static_cast<int64_t>(rbase) * 2048;
         const char* asrc = reinterpret_cast<const char*>(p.att) + static_cast<int64_t>(rbase) * 1024;
         const char* fsrc = reinterpret_cast<const char*>(p.fsmn) + static_cast<int64_t>(rbase) * 1024;
@@ -345,9 +483,13 @@ __global__ __launch_bounds__(kFfnThreads) void post_attn_kernel(const FfnParams 
     // ---- a projection pass: the row tile += afrag W^T for 512 output columns, 4 chunks of 8 pieces starting at
     //      chunk c0 of the stream, whose piece 0 every wave has seen land.  TO_W1: W1 pieces (256-byte rows) follow
     //      the pass and their first fragments are read ahead; otherwise the pass ends with nothing read ahead, which
-    //      leaves the registers to the output code behind it.
-    auto proj_pass = [&](int c0, auto to_w1) {
+    //      leaves the registers to the output code behind it.  FIRST: the output projection, whose chunk is a quarter
+    //      of the output columns over all of k (the others: a quarter of k over all columns, two k-slices per chunk);
+    //      with TILED it also adds residual tile 4 + i / 2 in the middle of every even piece i <= 22 and requests
+    //      tile 7 + i / 2 behind it.
+    auto proj_pass = [&](int c0, auto to_w1, auto first) {
         constexpr bool TO_W1 = decltype(to_w1)::value;
+        constexpr bool FIRST = decltype(first)::value;
         asm volatile("" : "+v"(rb2), "+v"(sw2));  // see chunk() below
         frag2_bases();
         static_for<8>([&](auto f) { wf[decltype(f)::value] = frag2(IC<0>{}, f); });
@@ -357,13 +499,33 @@ __global__ __launch_bounds__(kFfnThreads) void post_attn_kernel(const FfnParams 
             const char* cb1 = chunk_base(c0 + C + 1);
             static_for<8>([&](auto rc) {
                 constexpr int R = decltype(rc)::value;
-                constexpr int ks = 2 * C + (R >> 2), nq = R & 3;
+                constexpr int ks = FIRST ? R : 2 * C + (R >> 2), nq = FIRST ? C : (R & 3);
+                constexpr int PI = 8 * C + R;                        // piece of the pass
+                constexpr bool XADD = FIRST && TILED && PI % 2 == 0 && PI <= 22;
+                constexpr bool XLOAD = FIRST && TILED && xload_piece(PI);
+                constexpr int XSET = (PI / 2) % 3;
                 static_for<8>([&](auto f) {
                     constexpr int F = decltype(f)::value;
                     mfma_agpr<F16>(oacc[4 * nq + (F & 3)], wf[F], afrag[4 * ks + (F >> 2)]);
                     wf[F] = frag2(rc, IC<F + 8>{});
                 });
-                wait_vm_barrier<20>();
+                if constexpr (XADD) {
+                    constexpr int nt = 4 + PI / 2;
+                    wait_vm_barrier_regs<out_proj_vmcnt_x(PI)>(xr[XSET]);
+                    if (has_x) {
+                        f32x16 t = tile_out(oacc[nt]);
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) {
+                            t[4 * g] += xr[XSET][g][0]; t[4 * g + 1] += xr[XSET][g][1];
+                            t[4 * g + 2] += xr[XSET][g][2]; t[4 * g + 3] += xr[XSET][g][3];
+                        }
+                        tile_in(oacc[nt], t);
+                    }
+                } else if constexpr (FIRST && TILED) {
+                    wait_vm_barrier<out_proj_vmcnt(PI)>();
+                } else {
+                    wait_vm_barrier<20>();
+                }
                 static_for<8>([&](auto f) {
                     constexpr int F = decltype(f)::value;
                     mfma_agpr<F16>(oacc[4 * nq + (F & 3)], wf[F], afrag[4 * ks + 2 + (F >> 2)]);
@@ -375,6 +537,8 @@ __global__ __launch_bounds__(kFfnThreads) void post_attn_kernel(const FfnParams 
                     if constexpr ((F & 1) == 0) {
                         if constexpr (R == 0) stage_quarter(IC<7>{}, cb0, F >> 1);
                         else stage_quarter(IC<(R + 7) & 7>{}, cb1, F >> 1);
+                    } else if constexpr (XLOAD) {
+                        xload(IC<XSET>{}, 7 + PI / 2, IC<(F >> 1)>{});
                     }
                 });
             });
@@ -383,7 +547,7 @@ __global__ __launch_bounds__(kFfnThreads) void post_attn_kernel(const FfnParams 
 
     // ---- output projection: the row tile += att Wo^T
     FFN_STAMP();  // prologue done
-    proj_pass(0, std::true_type{});
+    proj_pass(0, std::true_type{}, std::true_type{});
     FFN_STAMP();  // output projection done
 
     // ---- x_mid is complete: row statistics, n(x_mid) as the operand fragments of W1, and b2 into the row tile.
@@ -517,12 +681,19 @@ __global__ __launch_bounds__(kFfnThreads) void post_attn_kernel(const FfnParams 
         //      from b_qkv.  The tile is then 512 columns of q, of k and of v in turn.
         asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");
         char* es = reinterpret_cast<char*>(b1s) + wave * 4096;
-        const int wr_row = l31 * 128, wr_sw = l31 & 7;
-        const int rd_row = lane >> 3, rd_c = lane & 7;
+        // (the lane number is taken afresh here: derived from the values of the prologue it keeps those alive, or
+        // spilled, over the whole kernel)
+        const int lane_e = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+        const int l31_e = lane_e & 31;
+        const int wr_row = l31_e * 128, wr_sw = l31_e & 7;
+        const int rd_row = lane_e >> 3, rd_c = lane_e & 7;
         // The slab rows leave through buffer stores: a row at or past M lies beyond the descriptor's size and is
         // dropped by the hardware, so no lane mask or branch surrounds a store, and the address is one 32-bit
         // per-lane offset plus an immediate.
-        const __amdgpu_buffer_rsrc_t xo_rsrc = __builtin_amdgcn_make_buffer_rsrc(p.x_out, 0, no_store ? 0 : p.M * 2048, 0x00020000);
+        // (the tiled residual stream holds whole 128-row tiles: the rows past M of the last one are written too)
+        const int xo_rows = TILED ? (p.M + kFfnRows - 1) / kFfnRows * kFfnRows : p.M;
+        const __amdgpu_buffer_rsrc_t xo_rsrc = __builtin_amdgcn_make_buffer_rsrc(p.x_out, 0, no_store ? 0 : xo_rows * 2048, 0x00020000);
+        const int xt_off = (row0 >> 5) * 65536 + lane_e * 16;
         const __amdgpu_buffer_rsrc_t qkv_rsrc = __builtin_amdgcn_make_buffer_rsrc(p.qkv, 0, no_store ? 0 : p.M * p.ldq * 2, 0x00020000);
         int xo_off[4], qkv_off[4];
 #pragma unroll
@@ -552,18 +723,28 @@ __global__ __launch_bounds__(kFfnThreads) void post_attn_kernel(const FfnParams 
 #pragma unroll
         for (int nt = 0; nt < 16; ++nt) {
             const f32x16 t = tile_out(oacc[nt]);
+            if constexpr (TILED) {
+                // the tile leaves in register order: quad g of every lane is one contiguous 1 KiB run
 #pragma unroll
-            for (int g = 0; g < 4; ++g)
-                *reinterpret_cast<float4*>(es + wr_row + (((2 * g + h) ^ wr_sw) << 4)) =
-                    make_float4(t[4 * g], t[4 * g + 1], t[4 * g + 2], t[4 * g + 3]);
-            ffn_wave_lds_sync();
+                for (int g = 0; g < 4; ++g) {
+                    const u32x4 v = {__float_as_uint(t[4 * g]), __float_as_uint(t[4 * g + 1]), __float_as_uint(t[4 * g + 2]),
+                                     __float_as_uint(t[4 * g + 3])};
+                    __builtin_amdgcn_raw_buffer_store_b128(v, xo_rsrc, xt_off + 1024 * g, 4096 * nt, 0);
+                }
+            } else {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int r = rd_row + 8 * i;
-                const u32x4 v = *reinterpret_cast<const u32x4*>(es + r * 128 + ((rd_c ^ (r & 7)) << 4));
-                __builtin_amdgcn_raw_buffer_store_b128(v, xo_rsrc, xo_off[i] + 128 * nt, 0, 0);
+                for (int g = 0; g < 4; ++g)
+                    *reinterpret_cast<float4*>(es + wr_row + (((2 * g + h) ^ wr_sw) << 4)) =
+                        make_float4(t[4 * g], t[4 * g + 1], t[4 * g + 2], t[4 * g + 3]);
+                ffn_wave_lds_sync();
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int r = rd_row + 8 * i;
+                    const u32x4 v = *reinterpret_cast<const u32x4*>(es + r * 128 + ((rd_c ^ (r & 7)) << 4));
+                    __builtin_amdgcn_raw_buffer_store_b128(v, xo_rsrc, xo_off[i] + 128 * nt, 0, 0);
+                }
+                ffn_wave_lds_sync();
             }
-            ffn_wave_lds_sync();
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
                 float v[8];
@@ -578,7 +759,7 @@ __global__ __launch_bounds__(kFfnThreads) void post_attn_kernel(const FfnParams 
         FFN_STAMP();  // x_out stored, n(x_out) in fragments
 #pragma unroll 1
         for (int pass = 0; pass < 3; ++pass) {
-            proj_pass(4 + nch + 4 * pass, std::false_type{});
+            proj_pass(4 + nch + 4 * pass, std::false_type{}, std::false_type{});
             FFN_STAMP();  // projection pass computed (the pass before it stored)
             asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");
             // two tiles make one 128-byte row piece; the slab is read back as whole rows
@@ -619,8 +800,10 @@ __global__ __launch_bounds__(kFfnThreads) void post_attn_kernel(const FfnParams 
     //      128-byte lines (8 consecutive lanes per row)
     char* es = smem + wave * 8192;  // fp32 slab of x_out
     char* ys = es + 4096;           // 16-bit slab of y
-    const int wr_row = l31 * 128, wr_sw = l31 & 7;
-    const int rd_row = lane >> 3, rd_c = lane & 7;
+    const int lane_e = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));  // (see the OUT 2 branch)
+    const int l31_e = lane_e & 31;
+    const int wr_row = l31_e * 128, wr_sw = l31_e & 7;
+    const int rd_row = lane_e >> 3, rd_c = lane_e & 7;
     float mean = 0.0f, m2 = 0.0f, rstd = 0.0f, shift = 0.0f;
     RowStat rs;
     if constexpr (HAS_Y) {
@@ -686,12 +869,16 @@ __global__ __launch_bounds__(kFfnThreads) void post_attn_kernel(const FfnParams 
 // The dynamic-LDS limit of a kernel is a per-device attribute: asrfe_create calls this with the context's device
 // current, before any compute call can run.
 int32_t prepare_post_attn(asrfe_ctx* ctx) {
-    const void* fns[6] = {reinterpret_cast<const void*>(post_attn_kernel<true, 0>),
-                          reinterpret_cast<const void*>(post_attn_kernel<true, 1>),
-                          reinterpret_cast<const void*>(post_attn_kernel<true, 2>),
-                          reinterpret_cast<const void*>(post_attn_kernel<false, 0>),
-                          reinterpret_cast<const void*>(post_attn_kernel<false, 1>),
-                          reinterpret_cast<const void*>(post_attn_kernel<false, 2>)};
+    const void* fns[10] = {reinterpret_cast<const void*>(post_attn_kernel<true, 0, false>),
+                           reinterpret_cast<const void*>(post_attn_kernel<true, 1, false>),
+                           reinterpret_cast<const void*>(post_attn_kernel<true, 2, false>),
+                           reinterpret_cast<const void*>(post_attn_kernel<false, 0, false>),
+                           reinterpret_cast<const void*>(post_attn_kernel<false, 1, false>),
+                           reinterpret_cast<const void*>(post_attn_kernel<false, 2, false>),
+                           reinterpret_cast<const void*>(post_attn_kernel<true, 0, true>),
+                           reinterpret_cast<const void*>(post_attn_kernel<true, 2, true>),
+                           reinterpret_cast<const void*>(post_attn_kernel<false, 0, true>),
+                           reinterpret_cast<const void*>(post_attn_kernel<false, 2, true>)};
     for (const void* f : fns)
         if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
             return set_err(ctx, ASRFE_ERR_HIP, "post_attn: cannot raise the dynamic LDS limit to 160 KiB");
@@ -706,22 +893,32 @@ int32_t launch_post_attn(asrfe_ctx* ctx, const FfnParams& p, hipStream_t s) {
         return set_err(ctx, ASRFE_ERR_BAD_ARG, "post_attn: null or misaligned argument");
     if (p.qkv && (p.y || !p.bqkv || p.ldq % 8 != 0 || p.ff > kPostAttnQkvMaxFf))
         return set_err(ctx, ASRFE_ERR_BAD_ARG, "post_attn: qkv output excludes y, needs b_qkv and linear_units <= 5632");
+    if (p.tiled && p.y)
+        return set_err(ctx, ASRFE_ERR_BAD_ARG, "post_attn: the tiled residual stream goes with the qkv output or with x_out alone");
     // (its stores address rows by signed 32-bit byte offsets, up to one row tile past M)
-    if (p.qkv && (static_cast<int64_t>(p.M) + kFfnRows) * std::max<int64_t>(2048, 2 * static_cast<int64_t>(p.ldq)) >= (int64_t{1} << 31))
+    if ((p.qkv || p.tiled) && (static_cast<int64_t>(p.M) + kFfnRows) * std::max<int64_t>(2048, 2 * static_cast<int64_t>(p.ldq)) >= (int64_t{1} << 31))
         return set_err(ctx, ASRFE_ERR_SHAPE, "post_attn: x_out and qkv must each stay below 2 GiB per launch");
     const int out = p.qkv ? 2 : (p.y ? 1 : 0);
     const int lds = kFfnRing + std::max(p.ff, kSlabFloats) * 4 + 2 * 512 * 4 + (out == 2 ? 1536 * 4 : 0);
     const dim3 grid((p.M + kFfnRows - 1) / kFfnRows), block(kFfnThreads);
     const bool f16 = ctx->cfg.enc_compute_dtype == ASRFE_DT_F16;
-#define POST_ATTN_LAUNCH(F, O) hipLaunchKernelGGL((post_attn_kernel<F, O>), grid, block, lds, s, p)
-    if (f16) {
-        if (out == 2) POST_ATTN_LAUNCH(true, 2);
-        else if (out == 1) POST_ATTN_LAUNCH(true, 1);
-        else POST_ATTN_LAUNCH(true, 0);
+#define POST_ATTN_LAUNCH(F, O, T) hipLaunchKernelGGL((post_attn_kernel<F, O, T>), grid, block, lds, s, p)
+    if (p.tiled) {
+        if (f16) {
+            if (out == 2) POST_ATTN_LAUNCH(true, 2, true);
+            else POST_ATTN_LAUNCH(true, 0, true);
+        } else {
+            if (out == 2) POST_ATTN_LAUNCH(false, 2, true);
+            else POST_ATTN_LAUNCH(false, 0, true);
+        }
+    } else if (f16) {
+        if (out == 2) POST_ATTN_LAUNCH(true, 2, false);
+        else if (out == 1) POST_ATTN_LAUNCH(true, 1, false);
+        else POST_ATTN_LAUNCH(true, 0, false);
     } else {
-        if (out == 2) POST_ATTN_LAUNCH(false, 2);
-        else if (out == 1) POST_ATTN_LAUNCH(false, 1);
-        else POST_ATTN_LAUNCH(false, 0);
+        if (out == 2) POST_ATTN_LAUNCH(false, 2, false);
+        else if (out == 1) POST_ATTN_LAUNCH(false, 1, false);
+        else POST_ATTN_LAUNCH(false, 0, false);
     }
 #undef POST_ATTN_LAUNCH
     const hipError_t e = hipGetLastError();

@@ -24,6 +24,7 @@ def main():
     ap.add_argument("--repeat", type=int, default=2)
     ap.add_argument("--flags", type=int, nargs="*", default=[0])
     ap.add_argument("--qkv", action="store_true", help="time the variant that also projects the next layer's q, k, v")
+    ap.add_argument("--tiled", action="store_true", help="residual stream in the kernel's register order (flags bit 9)")
     ap.add_argument("--lib", default=None, help="path of another build of libasrfe.so (A/B runs of experiment builds)")
     args = ap.parse_args()
     if args.lib:
@@ -43,6 +44,21 @@ def main():
         fsmn = (torch.randn(m, 512, device=dev) * 0.5).half()
         return att, fsmn
 
+    TILED = 512 if args.tiled else 0
+
+    def to_tiled(x):
+        """[m][512] row-major -> the kernel's register order, padded to whole 128-row tiles: per 32-row group
+        [tile nt 16][quad g 4][h 2][row 32][4 floats]."""
+        m = x.shape[0]
+        mp = (m + 127) // 128 * 128
+        xp = torch.zeros(mp, 512, device=x.device, dtype=x.dtype)
+        xp[:m] = x
+        return xp.view(mp // 32, 32, 16, 4, 2, 4).permute(0, 2, 3, 4, 1, 5).contiguous().view(mp, 512)
+
+    def from_tiled(xt, m):
+        mp = xt.shape[0]
+        return xt.view(mp // 32, 16, 4, 2, 32, 4).permute(0, 4, 1, 2, 3, 5).contiguous().view(mp, 512)[:m]
+
     if args.check:
         g = {k: v.to(dev).float() for k, v in sd.items()}
         pfx = "encoders0.0."
@@ -52,12 +68,19 @@ def main():
                 att, fsmn = tens(m)
                 xo = torch.empty_like(x)
                 y = torch.empty(m, 512, device=dev, dtype=torch.float16)
-                ctx.check(lib.asrfe_debug_post_attn(ctx.handle, 0, att.data_ptr(), fsmn.data_ptr(),
-                                                    x.data_ptr() if with_x else None, xo.data_ptr(), y.data_ptr(), None, m, 0, stream))
-                xo2 = torch.empty_like(x)
+                xin = to_tiled(x) if args.tiled else x
+                if args.tiled:  # x_out alone: tiled in, row-major out (the encoder's last layer); no y in this mode
+                    ctx.check(lib.asrfe_debug_post_attn(ctx.handle, 0, att.data_ptr(), fsmn.data_ptr(),
+                                                        xin.data_ptr() if with_x else None, xo.data_ptr(), None, None, m, TILED, stream))
+                    y = None
+                else:
+                    ctx.check(lib.asrfe_debug_post_attn(ctx.handle, 0, att.data_ptr(), fsmn.data_ptr(),
+                                                        x.data_ptr() if with_x else None, xo.data_ptr(), y.data_ptr(), None, m, 0, stream))
+                xo2 = torch.full(((m + 127) // 128 * 128, 512), float("nan"), device=dev)
                 qkv = torch.empty(m, 1536, device=dev, dtype=torch.float16)
                 ctx.check(lib.asrfe_debug_post_attn(ctx.handle, 0, att.data_ptr(), fsmn.data_ptr(),
-                                                    x.data_ptr() if with_x else None, xo2.data_ptr(), None, qkv.data_ptr(), m, 0, stream))
+                                                    xin.data_ptr() if with_x else None, xo2.data_ptr(), None, qkv.data_ptr(), m, TILED, stream))
+                xo2 = from_tiled(xo2, m) if args.tiled else xo2[:m]
                 xm = att.float() @ g[pfx + "self_attn.linear_out.weight"].half().float().T + g[pfx + "self_attn.linear_out.bias"] + fsmn.float()
                 if with_x:
                     xm = xm + x
@@ -68,13 +91,13 @@ def main():
                 n1 = torch.nn.functional.layer_norm(ref, (512,), g["encoders.0.norm1.weight"], g["encoders.0.norm1.bias"], 1e-12)
                 qref = n1 @ g["encoders.0.self_attn.linear_q_k_v.weight"].T + g["encoders.0.self_attn.linear_q_k_v.bias"]
                 e1 = (xo - ref).abs().max().item()
-                e2 = (y.float() - yref).abs().max().item()
+                e2 = (y.float() - yref).abs().max().item() if y is not None else 0.0
                 e3 = (qkv.float() - qref).abs().max().item()
                 print(f"check m={m} x={'yes' if with_x else 'no '}: x_out err {e1:.3e}, y err {e2:.3e}, qkv err {e3:.3e}, "
                       f"x_out of both variants equal: {torch.equal(xo, xo2)}")
                 assert e1 < 3e-3 and e2 < 1e-2 and e3 < 2e-2 and torch.equal(xo, xo2)
     m = args.rows
-    x = torch.randn(m, 512, device=dev)
+    x = torch.randn((m + 127) // 128 * 128, 512, device=dev)
     y = torch.empty(m, 512, device=dev, dtype=torch.float16)
     att, fsmn = tens(m)
 
@@ -82,8 +105,8 @@ def main():
 
     def launch(flags):
         ctx.check(lib.asrfe_debug_post_attn(ctx.handle, 0, att.data_ptr(), fsmn.data_ptr(), x.data_ptr(), x.data_ptr(),
-                                            None if args.qkv else y.data_ptr(), qkv.data_ptr() if args.qkv else None,
-                                            m, flags, stream))
+                                            None if (args.qkv or args.tiled) else y.data_ptr(), qkv.data_ptr() if args.qkv else None,
+                                            m, flags | TILED, stream))
 
     import time
     t0 = time.time()
@@ -115,7 +138,7 @@ def main():
         tr = torch.zeros(64, dtype=torch.int64, device=dev)
         for _ in range(3):
             ctx.check(lib.asrfe_debug_post_attn(ctx.handle, 0, att.data_ptr(), fsmn.data_ptr(), x.data_ptr(), x.data_ptr(),
-                                                tr.data_ptr(), qkv.data_ptr(), m, 256, stream))
+                                                tr.data_ptr(), qkv.data_ptr(), m, 256 | TILED, stream))
         torch.cuda.synchronize()
         t = [v for v in tr.cpu().tolist() if v]
         names = ["prologue", "out-proj", "LayerNorm", "feed-forward", "x_out + fragments", "q pass", "k pass", "v pass", "stores"]
