@@ -440,7 +440,9 @@ def test_post_attention_kernel_vs_fp64(pkg):
         assert torch.equal(xo, xo2), (m, with_x)
         assert float((qkv.double() - qref).abs().max()) <= 2e-2, (m, with_x)
         # the residual stream in the kernel's register order (flags bit 9; what the encoder's throughput plan passes
-        # from layer to layer): the same numbers bit for bit, whole 128-row tiles per buffer
+        # from layer to layer), whole 128-row tiles per buffer.  The same sums in another order (the residual joins
+        # the first 128 columns after the projection, the others before it): equal to fp32 rounding where no 16-bit
+        # rounding of a normalised value flips, within 1e-3 where some do (each variant meets the fp64 bar by itself)
         mp = (m + 127) // 128 * 128
         xt = torch.zeros(mp, 512, device="cuda")
         xt[:m] = x
@@ -448,14 +450,16 @@ def test_post_attention_kernel_vs_fp64(pkg):
         xo3 = torch.empty_like(x)  # tiled in, row-major out: the encoder's last layer
         ctx.check(ctx.lib.asrfe_debug_post_attn(ctx.handle, 0, att.data_ptr(), fsmn.data_ptr(),
                                                 xt.data_ptr() if with_x else None, xo3.data_ptr(), None, None, m, 512, stream))
-        assert torch.equal(xo, xo3), (m, with_x)
+        assert float((xo - xo3).abs().max()) <= 1e-3, (m, with_x)  # (16-bit roundings of n(x_mid) may flip)
+        assert float((xo3.double() - ref).abs().max()) <= 2e-3, (m, with_x)
         xo4 = torch.full((mp // 32, 16, 4, 2, 32, 4), float("nan"), device="cuda")  # tiled in and out, with q, k, v
         qkv4 = torch.empty_like(qkv)
         ctx.check(ctx.lib.asrfe_debug_post_attn(ctx.handle, 0, att.data_ptr(), fsmn.data_ptr(),
                                                 xt.data_ptr() if with_x else None, xo4.data_ptr(), None, qkv4.data_ptr(), m, 512,
                                                 stream))
-        assert torch.equal(xo, xo4.permute(0, 4, 1, 2, 3, 5).reshape(mp, 512)[:m]), (m, with_x)
-        assert torch.equal(qkv, qkv4), (m, with_x)
+        assert torch.equal(xo3, xo4.permute(0, 4, 1, 2, 3, 5).reshape(mp, 512)[:m]), (m, with_x)
+        assert float((qkv.float() - qkv4.float()).abs().max()) <= 4e-3, (m, with_x)
+        assert float((qkv4.double() - qref).abs().max()) <= 2e-2, (m, with_x)
 
 
 def test_fused_and_unfused_encoder_paths_agree(pkg, monkeypatch):
@@ -486,8 +490,8 @@ def test_fused_and_unfused_encoder_paths_agree(pkg, monkeypatch):
     assert float((outs[0] - outs[3]).abs().max()) <= 4e-3
     assert not torch.equal(outs[0], outs[3])  # the latency plan really is another sequence of kernels
     # ASRFE_ROW_MAJOR_X=1 keeps the residual stream row-major between the post-attention launches (the throughput plan
-    # otherwise hands it on in the kernel's register order): the same arithmetic in the same order
-    assert torch.equal(outs[0], outs[4])
+    # otherwise hands it on in the kernel's register order and adds it at another point of the same sum)
+    assert float((outs[0] - outs[4]).abs().max()) <= 2e-3
 
 
 def test_engine_streams_give_identical_results(pkg):

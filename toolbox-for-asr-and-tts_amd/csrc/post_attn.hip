@@ -126,26 +126,37 @@ __device__ __forceinline__ void wait_vm_barrier_regs(f32x4 (&r)[4]) {
 }
 
 // ---- vector-memory bookkeeping of the output projection when the residual stream arrives beside it (TILED) ----
-// Before the pass the wave has issued weight pieces 0..6; piece i of the pass issues piece i + 7 (four DMA loads, at
-// MFMAs 0, 2, 4, 6 of its second half) and, when i is even and at most 16, the four loads of residual tile 7 + i / 2
-// (at MFMAs 1, 3, 5, 7).  In the middle of piece i the wave needs piece i + 1 and, when i is even and at most 22,
-// residual tile 4 + i / 2 (loaded by piece i - 6, or before the pass).
-constexpr int xload_piece(int j) { return (j >= 0 && j <= 16 && j % 2 == 0) ? 1 : 0; }
-// operations younger than the last DMA load of piece i + 1 at that point
+// Before the pass the wave has issued weight pieces 0..7, in that order.  Piece i >= 1 of the pass issues piece i + 7
+// (four DMA loads, at MFMAs 0, 2, 4, 6 of its second half); an even piece i <= 24 also issues the four loads of a
+// residual tile (at MFMAs 1, 3, 5, 7): the tile that piece i + 6 adds.  In the middle of piece i the wave needs piece
+// i + 1 and, when i is even, the residual tile it adds there (loaded by piece i - 6, or before the pass).
+// Even piece 2 k adds tile 4 + k for k < 12 (a tile of the NEXT column quarter, not yet started) and tile k - 12
+// after that (the first quarter's tiles, long finished by then).
+constexpr int xtile_of(int k) { return k < 12 ? 4 + k : k - 12; }
+constexpr int xload_piece(int j) { return (j >= 0 && j <= 24 && j % 2 == 0) ? 1 : 0; }
+// vector-memory operations piece j of the pass issues
+constexpr int out_proj_ops(int j) { return (j >= 1 ? 4 : 0) + 4 * xload_piece(j); }
+// operations younger than the last DMA load of piece i + 1 at the middle of piece i
 constexpr int out_proj_vmcnt(int i) {
     int n = 0;
-    if (i + 1 <= 6) {
-        n = 4 * (6 - (i + 1));
-        for (int j = 0; j < i; ++j) n += 4 + 4 * xload_piece(j);
+    if (i + 1 <= 7) {
+        n = 4 * (7 - (i + 1));
+        for (int j = 0; j < i; ++j) n += out_proj_ops(j);
     } else {
-        n = xload_piece(i - 6);
-        for (int j = i - 5; j < i; ++j) n += 4 + 4 * xload_piece(j);
+        n = xload_piece(i - 6);  // (its last load follows the last DMA load of piece i + 1)
+        for (int j = i - 5; j < i; ++j) n += out_proj_ops(j);
     }
     return n;
 }
-// ... and younger than the last load of the residual tile that piece i adds (that load is the last operation of
-// piece i - 6, one behind the DMA loads of piece i + 1)
-constexpr int out_proj_vmcnt_x(int i) { return i >= 6 ? out_proj_vmcnt(i) - 1 : out_proj_vmcnt(i); }
+// ... and younger than both that and the last load of the residual tile that even piece i adds: the tile was
+// requested by piece i - 6 as its last operation (before the pass for i < 6, behind every weight piece up to 7 but
+// in front of every slab, so it has long arrived)
+constexpr int out_proj_vmcnt_x(int i) {
+    if (i < 6) return out_proj_vmcnt(i);
+    int n = 0;
+    for (int j = i - 5; j < i; ++j) n += out_proj_ops(j);
+    return n < out_proj_vmcnt(i) ? n : out_proj_vmcnt(i);
+}
 
 // Row statistics of a lane's 256 values (16 tiles of 16): sums of (x - k) and (x - k)^2 with k = the mean of the
 // lane's first tile, two values per packed instruction (1.5 instructions per value).  The shift keeps the variance
@@ -204,8 +215,8 @@ __device__ __forceinline__ u16x8 pack8(float a0, float a1, float a2, float a3, f
 // (block (32-row group, tile nt, quad g) = 64 lanes x 16 bytes: lane l31 + 32 h holds columns 32 nt + 8 g + 4 h .. + 3
 // of row l31), so a wave reads and writes it as whole 1 KiB runs straight from / into registers, with no trip through
 // LDS.  x is read in that order; x_out is written in it for OUT 2 and row-major otherwise (the encoder's last layer).
-// Only the tiles of the first column quarter are added before the output projection starts; the other twelve arrive
-// while it runs and are added to their (not yet started) quarter's tiles between its MFMAs.
+// No residual tile is waited for before the output projection starts: they arrive while it runs and are added
+// between its MFMAs, twelve to tiles of column quarters that have not started yet, the first quarter's four at the end.
 template <bool F16, int OUT, bool TILED>
 __global__ __launch_bounds__(kFfnThreads) void post_attn_kernel(const FfnParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -254,9 +265,10 @@ __global__ __launch_bounds__(kFfnThreads) void post_attn_kernel(const FfnParams 
 #pragma unroll
         for (int i = 0; i < 4; ++i) stage_quarter(rc, cbase, i);
     };
-    // the first four pieces fly while the activations are loaded; slots 4..7 serve as their staging until then
+    // the first pieces fly while the activations are loaded; the other slots serve as their staging until then
     const char* cb_first = chunk_base(0);
-    stage(IC<0>{}, cb_first); stage(IC<1>{}, cb_first); stage(IC<2>{}, cb_first); stage(IC<3>{}, cb_first);
+    stage(IC<0>{}, cb_first); stage(IC<1>{}, cb_first);
+    if constexpr (!TILED) { stage(IC<2>{}, cb_first); stage(IC<3>{}, cb_first); }  // (TILED: slots 2..7 stage activations)
 
     for (int i = tid * 4; i < p.ff; i += kFfnThreads * 4)
         *reinterpret_cast<float4*>(b1s + i) = *reinterpret_cast<const float4*>(p.b1 + i);
@@ -276,9 +288,8 @@ __global__ __launch_bounds__(kFfnThreads) void post_attn_kernel(const FfnParams 
     f32x16 oacc[16];
     u16x8 afrag[32];  // att, later n(x_mid), as operand fragments: fragment s covers k = 16 s .. 16 s + 15
     const bool has_x = p.x != nullptr;  // layer 0 has no residual into the attention block: x counts as zero
-    // TILED: four register sets for residual tiles; tiles 0..3 use all four before the projection, tiles 4..15 rotate
-    // through sets 0..2 while it runs
-    f32x4 xr[4][4];
+    // TILED: three register sets that the residual tiles rotate through: set k % 3 for the tile that piece 2 k adds
+    f32x4 xr[3][4];
     const uint32_t lane16 = lane * 16;
     // the wave's 32-row group of the tiled residual stream (64 KiB); layer 0 reads (and ignores) the first 64 KiB of
     // the weight stream instead, so that the count of loads in flight is the same in every layer
@@ -288,13 +299,15 @@ __global__ __launch_bounds__(kFfnThreads) void post_attn_kernel(const FfnParams 
         gload16<G * 1024>(xr[S][G], xtile + nt * 4096, lane16);
     };
     if constexpr (TILED) {
-        static_for<4>([&](auto sc) {
-            static_for<4>([&](auto gc) { xload(sc, decltype(sc)::value, gc); });
+        // att and fsmn come in by LDS-DMA as slabs of 32 rows x 128 bytes; the residual stream does not pass through
+        // here at all.  A wave's slab slot j is the part of ring slot 2 + j that the same wave later fills with its
+        // share of weight piece 2 + j (the four 1 KiB runs at wave * 1 KiB + k * 4 KiB), so it can stage that piece
+        // as soon as it has read its own last slab there, without asking the other waves.  Six slots: five slabs in
+        // flight behind the one being read.  Slab I uses slot (I + 2) % 6, which makes the last six slabs free slots
+        // 0..5 in order: pieces 2..7 are requested in stream order.
+        static_for<3>([&](auto sc) {
+            static_for<4>([&](auto gc) { xload(sc, xtile_of(decltype(sc)::value), gc); });
         });
-    }
-    if constexpr (TILED) {
-        const uint32_t xs_lds = __builtin_amdgcn_readfirstlane(smem_base + (4 + wave) * kPieceBytes);
-        const char* xs = smem + (4 + wave) * kPieceBytes;
         const int rbase = min(row0, p.M - 1);
         const char* asrc = reinterpret_cast<const char*>(p.att) + static_cast<int64_t>(rbase) * 1024;
         const char* fsrc = reinterpret_cast<const char*>(p.fsmn) + static_cast<int64_t>(rbase) * 1024;
@@ -305,27 +318,24 @@ __global__ __launch_bounds__(kFfnThreads) void post_attn_kernel(const FfnParams 
             const int rr = min(row0 + r, p.M - 1) - rbase;
             aoff[k] = static_cast<uint32_t>(rr * 1024 + (((lane & 7) ^ (r & 7)) << 4));
         }
-        // slabs 0..7: att k-slices, slabs 8..15: fsmn column pairs of tiles (2 p, 2 p + 1)
+        const uint32_t sl_lds = __builtin_amdgcn_readfirstlane(smem_base + 2 * kPieceBytes + wave * 1024);
+        // slabs 0..7: att k-slices, slabs 8..15: fsmn column pairs of tiles (2 p, 2 p + 1); rows 8 k .. 8 k + 7 of a
+        // slab sit at k * 4 KiB
         auto slab_dma = [&](auto ic) {
             constexpr int I = decltype(ic)::value;
-            const uint32_t dst = xs_lds + (I & 3) * 4096;
+            const uint32_t dst = sl_lds + ((I + 2) % 6) * kPieceBytes;
             const char* src = I < 8 ? asrc + I * 128 : fsrc + (I - 8) * 128;
 #pragma unroll
-            for (int k = 0; k < 4; ++k) lds_dma16(src, aoff[k], dst + k * 1024);
+            for (int k = 0; k < 4; ++k) lds_dma16(src, aoff[k], dst + k * 4096);
         };
-        slab_dma(IC<0>{}); slab_dma(IC<1>{}); slab_dma(IC<2>{}); slab_dma(IC<3>{});
+        static_for<6>([&](auto ic) { slab_dma(ic); });
         uint2 fs[8];
         static_for<16>([&](auto ic) {
             constexpr int I = decltype(ic)::value;
-            // Loads in flight behind slab I: the three slabs after it, and from slab 10 on the twelve loads of
-            // residual tiles 4..6, which are issued between slabs 13 and 14.  The residual tiles 0..3 were requested
-            // before any slab, so they have arrived with the first one.
-            if constexpr (I <= 9) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-            else if constexpr (I <= 12) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
-            else if constexpr (I == 13) asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
-            else if constexpr (I == 14) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            const char* sl = xs + (I & 3) * 4096 + l31 * 128;
+            // behind slab I in the queue: the slabs up to I + 5 and the weight pieces requested so far, 20 loads in
+            // every iteration
+            asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
+            const char* sl = smem + (2 + (I + 2) % 6) * kPieceBytes + wave * 1024 + (l31 >> 3) * 4096 + (l31 & 7) * 128;
             const int sw = l31 & 7;
             if constexpr (I < 8) {
 #pragma unroll
@@ -340,7 +350,6 @@ __global__ __launch_bounds__(kFfnThreads) void post_attn_kernel(const FfnParams 
                 static_for<2>([&](auto nsc) {
                     constexpr int ns = decltype(nsc)::value, nt = 2 * P + ns;
                     f32x16 t;
-                    if constexpr (nt < 4) wait_vm_regs<63>(xr[nt]);  // (arrived long ago: this only names the registers)
 #pragma unroll
                     for (int g = 0; g < 4; ++g) {
                         float f0, f1, f2, f3;
@@ -348,26 +357,13 @@ __global__ __launch_bounds__(kFfnThreads) void post_attn_kernel(const FfnParams 
                         unpack_elem2<F16>(fs[4 * ns + g].y, f2, f3);
                         const float4 bo4 = *reinterpret_cast<const float4*>(bos + 32 * nt + 8 * g + 4 * h);
                         t[4 * g] = f0 + bo4.x; t[4 * g + 1] = f1 + bo4.y; t[4 * g + 2] = f2 + bo4.z; t[4 * g + 3] = f3 + bo4.w;
-                        if constexpr (nt < 4) {
-                            if (has_x) {
-                                t[4 * g] += xr[nt][g][0]; t[4 * g + 1] += xr[nt][g][1];
-                                t[4 * g + 2] += xr[nt][g][2]; t[4 * g + 3] += xr[nt][g][3];
-                            }
-                        }
                     }
                     tile_in(oacc[nt], t);
                 });
             }
-            if constexpr (I + 4 < 16) slab_dma(IC<I + 4>{});
-            if constexpr (I == 9) {
-                static_for<3>([&](auto sc) {
-                    static_for<4>([&](auto gc) { xload(sc, 4 + decltype(sc)::value, gc); });
-                });
-            }
+            if constexpr (I + 6 < 16) slab_dma(IC<I + 6>{});
+            else stage(IC<I - 8>{}, cb_first);  // the slot just read takes this wave's share of weight piece I - 8
         });
-        // every wave is done with its slabs: slots 4..6 can take their weight pieces
-        __syncthreads();
-        stage(IC<4>{}, cb_first); stage(IC<5>{}, cb_first); stage(IC<6>{}, cb_first);
     } else {
         const uint32_t xs_lds = __builtin_amdgcn_readfirstlane(smem_base + (4 + wave) * kPieceBytes);
         const char* xs = smem + (4 + wave) * kPieceBytes;
@@ -485,8 +481,8 @@ __global__ __launch_bounds__(kFfnThreads) void post_attn_kernel(const FfnParams 
     //      the pass and their first fragments are read ahead; otherwise the pass ends with nothing read ahead, which
     //      leaves the registers to the output code behind it.  FIRST: the output projection, whose chunk is a quarter
     //      of the output columns over all of k (the others: a quarter of k over all columns, two k-slices per chunk);
-    //      with TILED it also adds residual tile 4 + i / 2 in the middle of every even piece i <= 22 and requests
-    //      tile 7 + i / 2 behind it.
+    //      with TILED every even piece also adds a residual tile in its middle and requests the tile that the
+    //      piece six further on adds (out_proj_vmcnt above has the schedule).
     auto proj_pass = [&](int c0, auto to_w1, auto first) {
         constexpr bool TO_W1 = decltype(to_w1)::value;
         constexpr bool FIRST = decltype(first)::value;
@@ -501,7 +497,7 @@ __global__ __launch_bounds__(kFfnThreads) void post_attn_kernel(const FfnParams 
                 constexpr int R = decltype(rc)::value;
                 constexpr int ks = FIRST ? R : 2 * C + (R >> 2), nq = FIRST ? C : (R & 3);
                 constexpr int PI = 8 * C + R;                        // piece of the pass
-                constexpr bool XADD = FIRST && TILED && PI % 2 == 0 && PI <= 22;
+                constexpr bool XADD = FIRST && TILED && PI % 2 == 0;
                 constexpr bool XLOAD = FIRST && TILED && xload_piece(PI);
                 constexpr int XSET = (PI / 2) % 3;
                 static_for<8>([&](auto f) {
@@ -510,7 +506,9 @@ __global__ __launch_bounds__(kFfnThreads) void post_attn_kernel(const FfnParams 
                     wf[F] = frag2(rc, IC<F + 8>{});
                 });
                 if constexpr (XADD) {
-                    constexpr int nt = 4 + PI / 2;
+                    // (the tile moves through working registers as a whole: element-wise updates of an accumulation
+                    // tile make the compiler copy all sixteen registers per element)
+                    constexpr int nt = xtile_of(PI / 2);
                     wait_vm_barrier_regs<out_proj_vmcnt_x(PI)>(xr[XSET]);
                     if (has_x) {
                         f32x16 t = tile_out(oacc[nt]);
@@ -535,10 +533,14 @@ __global__ __launch_bounds__(kFfnThreads) void post_attn_kernel(const FfnParams 
                         wf[F] = frag2(IC<((R + 1) & 7)>{}, f);
                     }
                     if constexpr ((F & 1) == 0) {
-                        if constexpr (R == 0) stage_quarter(IC<7>{}, cb0, F >> 1);
-                        else stage_quarter(IC<(R + 7) & 7>{}, cb1, F >> 1);
+                        if constexpr (R == 0) {
+                            // (TILED: the first pass finds its piece 7 already requested by the prologue)
+                            if constexpr (!(FIRST && TILED && C == 0)) stage_quarter(IC<7>{}, cb0, F >> 1);
+                        } else {
+                            stage_quarter(IC<(R + 7) & 7>{}, cb1, F >> 1);
+                        }
                     } else if constexpr (XLOAD) {
-                        xload(IC<XSET>{}, 7 + PI / 2, IC<(F >> 1)>{});
+                        xload(IC<XSET>{}, xtile_of(PI / 2 + 3), IC<(F >> 1)>{});
                     }
                 });
             });
