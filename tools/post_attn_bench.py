@@ -24,13 +24,15 @@ def main():
     ap.add_argument("--repeat", type=int, default=2)
     ap.add_argument("--flags", type=int, nargs="*", default=[0])
     ap.add_argument("--qkv", action="store_true", help="time the variant that also projects the next layer's q, k, v")
+    ap.add_argument("--layers", type=int, default=2, help="encoder blocks to load; the timed launches walk through them "
+                    "(50: every launch meets weights that no cache holds, as inside the encoder)")
     ap.add_argument("--tiled", action="store_true", help="residual stream in the kernel's register order (flags bit 9)")
     ap.add_argument("--lib", default=None, help="path of another build of libasrfe.so (A/B runs of experiment builds)")
     args = ap.parse_args()
     if args.lib:
         pkg._lib.LIB_PATH = os.path.abspath(args.lib)
-    enc = pkg.SANMEncoder(num_blocks=2)
-    sd = encoder_state_dict(num_blocks=2, seed=3)
+    enc = pkg.SANMEncoder(num_blocks=args.layers)
+    sd = encoder_state_dict(num_blocks=args.layers, seed=3)
     gen = torch.Generator().manual_seed(5)
     for k in sd:  # non-trivial LayerNorm parameters and biases, so that a column mix-up shows
         if "norm" in k or k.endswith(".bias"):
@@ -103,8 +105,11 @@ def main():
 
     qkv = torch.empty(m, 1536, device=dev, dtype=torch.float16)
 
+    walk = [0]
+
     def launch(flags):
-        ctx.check(lib.asrfe_debug_post_attn(ctx.handle, 0, att.data_ptr(), fsmn.data_ptr(), x.data_ptr(), x.data_ptr(),
+        walk[0] = (walk[0] + 1) % (args.layers - 1)
+        ctx.check(lib.asrfe_debug_post_attn(ctx.handle, walk[0], att.data_ptr(), fsmn.data_ptr(), x.data_ptr(), x.data_ptr(),
                                             None if (args.qkv or args.tiled) else y.data_ptr(), qkv.data_ptr() if args.qkv else None,
                                             m, flags | TILED, stream))
 
