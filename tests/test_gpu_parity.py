@@ -805,10 +805,14 @@ def test_websocket_session_finalizes_through_the_engine(pkg):
     assert torch.equal(seen["lens"].cpu(), wl.cpu()) and torch.equal(seen["out"][:, :n].cpu(), want[:, :n].cpu())
 
 
-def test_attention_fsmn_kernel_vs_fp64(pkg):
+@pytest.mark.parametrize("pingpong", ["0", "1"])
+def test_attention_fsmn_kernel_vs_fp64(pkg, monkeypatch, pingpong):
     """The attention + FSMN kernel on its own (debug hook) against an fp64 evaluation of the same 16-bit inputs:
-    ragged lengths, a length below the FSMN half-width, T' around the 64-key and 128-query tile edges."""
+    ragged lengths, a length below the FSMN half-width, T' around the 64-key and 128- / 256-query tile edges.  Once with
+    the default kernel (128 query rows per workgroup) and once with ASRFE_ATTN_PINGPONG=1, under which query axes of
+    more than 128 rows take the 256-row kernel whose wave groups alternate on the matrix pipe."""
     import ctypes as C
+    monkeypatch.setenv("ASRFE_ATTN_PINGPONG", pingpong)
     cfg = so.SanmConfig(num_blocks=1)
     sd = so.make_state_dict(cfg, seed=2, dtype=torch.float32)
     gen = torch.Generator().manual_seed(3)
@@ -818,7 +822,8 @@ def test_attention_fsmn_kernel_vs_fp64(pkg):
     ctx = enc.ctx
     stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
     w = sd["encoders0.0.self_attn.fsmn_block.weight"].double().cuda()
-    for T, ll in [(1, [1]), (7, [7, 3]), (64, [64, 5]), (65, [65, 64, 2]), (129, [129, 128, 127]), (300, [300, 191, 64, 6])]:
+    for T, ll in [(1, [1]), (7, [7, 3]), (64, [64, 5]), (65, [65, 64, 2]), (129, [129, 128, 127]), (256, [256, 1, 0]),
+                  (257, [257, 193]), (300, [300, 191, 64, 6]), (513, [513, 449, 65])]:
         B = len(ll)
         qkv = (torch.randn(B, T, 1536, generator=gen) * 1.5).half().cuda()
         lens = torch.tensor(ll, dtype=torch.int32, device="cuda")
@@ -837,7 +842,9 @@ def test_attention_fsmn_kernel_vs_fp64(pkg):
         fref = (torch.nn.functional.conv1d(torch.nn.functional.pad(vm.transpose(1, 2), (5, 5)), w, groups=512).transpose(1, 2)
                 + vm) * mask[..., None]
         assert torch.isfinite(att.float()).all() and torch.isfinite(fsmn.float()).all()  # padded rows too: they feed later layers
-        assert float(((att.double() - ref) * mask[..., None]).abs().max()) <= 4e-3, (T, ll)
+        # (an utterance without keys has no defined attention output: only finiteness is asked of its rows)
+        err = torch.where(mask[..., None], att.double() - ref, torch.zeros_like(ref))
+        assert float(err.abs().max()) <= 4e-3, (T, ll)
         assert float((fsmn.double() - fref).abs().max()) <= 8e-3, (T, ll)
         assert float((fsmn.float() * (~mask[..., None])).abs().max()) == 0.0
 
