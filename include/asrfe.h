@@ -322,7 +322,10 @@ int32_t asrfe_debug_gemm(asrfe_ctx* ctx, const void* a, int32_t lda, const void*
  * dtype (the next norm1's scale and shift are folded into the next layer's QKV weights).  When qkv is not NULL
  * (y must be NULL then, and `layer` must not be the last) the kernel also projects the next layer's
  * qkv [m][1536] = norm1(x_out) Wqkv^T + b_qkv in the compute dtype, as asrfe_encoder_forward has it do.
- * flags != 0 are timing experiments that produce wrong results. */
+ * flags bit 9 (512): x is given in the order asrfe_encoder_forward keeps the residual stream in between two launches
+ * of this kernel, and x_out is written in it when qkv is set (row-major otherwise; y must be NULL): buffers of whole
+ * 128-row tiles, per 32-row group [tile 16][quad 4][h 2][row 32][4 floats] with the 4 floats = columns
+ * 32 tile + 8 quad + 4 h .. + 3 of the row.  The other flag bits are timing experiments that produce wrong results. */
 int32_t asrfe_debug_post_attn(asrfe_ctx* ctx, int32_t layer, const void* att, const void* fsmn, const float* x,
                               float* x_out, void* y, void* qkv, int32_t m, int32_t flags, void* stream);
 
