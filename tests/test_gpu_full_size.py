@@ -91,6 +91,13 @@ def test_bench_batch_64x30s_matches_oracle_fixture(pkg):
     out1 = eng.run_single_stream(dev(pcm), lens)[0]
     torch.cuda.synchronize()
     assert torch.equal(out1[clips].cpu(), torch.from_numpy(got))
+    # and the step repeats bit for bit, all 32000 rows of it (the post-attention kernel counts its loads in flight by
+    # hand: a count that is too loose somewhere would show as rows that differ from run to run)
+    first = out.clone()
+    for _ in range(12):
+        again = eng.run(dev(pcm), lens)[0]
+        torch.cuda.synchronize()
+        assert torch.equal(again, first)
     # the three clips alone, under the same (throughput) launch plan: the same rows
     from toolbox_for_asr_and_tts_amd import _lib
     cfg0 = _lib.default_config()
