@@ -805,6 +805,46 @@ def test_websocket_session_finalizes_through_the_engine(pkg):
     assert torch.equal(seen["lens"].cpu(), wl.cpu()) and torch.equal(seen["out"][:, :n].cpu(), want[:, :n].cpu())
 
 
+@pytest.mark.parametrize("height", [1, 2])
+def test_gemm_kernel_both_tile_heights_vs_fp64(pkg, height):
+    """The general GEMM (debug hook) with its tile height forced (flags bits 8-9: 1 = 256 rows, 2 = 128 rows; unforced,
+    the launch takes 128 rows where 256 would leave CUs idle): every epilogue, row counts that end inside a tile and
+    inside a wave's share, K from one pair of K-tiles up, against an fp64 product of the same fp16 operands."""
+    import ctypes as C
+
+    ctx = pkg.SANMEncoder(num_blocks=1).ctx
+    stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    gen = torch.Generator().manual_seed(60 + height)
+    for (m, n, k, epi) in [(1, 256, 128, 0), (129, 256, 128, 1), (300, 512, 256, 2), (513, 512, 384, 1), (1000, 768, 640, 2),
+                           (257, 256, 2048, 0), (4100, 512, 512, 2)]:
+        a = (torch.randn(m, k, generator=gen) * 0.5).half().cuda()
+        w = (torch.randn(n, k, generator=gen) * 0.05).half().cuda()
+        bias = torch.randn(n, generator=gen).cuda()
+        add16 = torch.randn(m, n, generator=gen).half().cuda()
+        add32 = torch.randn(m, n, generator=gen).cuda()
+        guard = 64  # rows behind the output keep their fill
+        out = torch.full((m + guard, n), 7.0, device="cuda", dtype=torch.float32 if epi == 2 else torch.float16)
+        outs = []
+        for flags in (height << 8, 0):
+            out[:m] = 0
+            ctx.check(ctx.lib.asrfe_debug_gemm(ctx.handle, a.data_ptr(), k, w.data_ptr(), k, bias.data_ptr(), m, n, k,
+                                               out.data_ptr(), n, add16.data_ptr() if epi == 2 else None,
+                                               add32.data_ptr() if epi == 2 else None, epi, flags, stream))
+            torch.cuda.synchronize()
+            assert bool((out[m:] == 7.0).all()), (m, n, k, epi, flags)
+            outs.append(out[:m].clone())
+        ref = a.double() @ w.double().T + bias.double()
+        if epi == 1:
+            ref = torch.relu(ref)
+        if epi == 2:
+            ref = ref + add16.double() + add32.double()
+        for o in outs:
+            err = (o.double() - ref).abs().max().item()
+            assert err < (2e-5 if epi == 2 else 4e-3), (m, n, k, epi, err)
+        # the K loop visits the same k in the same order at either height: the unforced launch gives the same bits
+        assert torch.equal(outs[0], outs[1])
+
+
 @pytest.mark.parametrize("pingpong", ["0", "1"])
 def test_attention_fsmn_kernel_vs_fp64(pkg, monkeypatch, pingpong):
     """The attention + FSMN kernel on its own (debug hook) against an fp64 evaluation of the same 16-bit inputs:

@@ -286,7 +286,23 @@ __global__ __launch_bounds__(256) void argmax_kernel(const float* __restrict__ l
     const float* src = logits + static_cast<int64_t>(row) * ld;
     float best = -INFINITY;
     int bi = 0x7fffffff;
-    for (int c = lane; c < vocab; c += 64) {
+    // 16 bytes per lane and four requests in flight where the row allows it; a lane meets its columns in rising order
+    // either way, so the strict comparison keeps the lowest index of equal values
+    int c0 = 0;
+    if ((ld & 3) == 0 && (reinterpret_cast<uintptr_t>(logits) & 15) == 0) {
+        const int nq = vocab >> 2;
+        const float4* s4 = reinterpret_cast<const float4*>(src);
+#pragma unroll 4
+        for (int q = lane; q < nq; q += 64) {
+            const float4 v = s4[q];
+            if (v.x > best) { best = v.x; bi = 4 * q; }
+            if (v.y > best) { best = v.y; bi = 4 * q + 1; }
+            if (v.z > best) { best = v.z; bi = 4 * q + 2; }
+            if (v.w > best) { best = v.w; bi = 4 * q + 3; }
+        }
+        c0 = nq * 4;
+    }
+    for (int c = c0 + lane; c < vocab; c += 64) {
         const float v = src[c];
         if (v > best) { best = v; bi = c; }
     }

@@ -25,6 +25,13 @@
 //
 //   Workgroup ids are remapped so that each of the 8 XCDs (private L2s) walks a contiguous range of tiles:
 //   the tiles sharing an activation panel run on one XCD at about the same time.
+//
+//   Half-height variant (MS = 1).  A product with few output tiles (16384 rows x 512 columns: 128 tiles of 256 x 256
+//   on 256 CUs) leaves half the chip idle, so launch_gemm then takes tiles of 128 (m) x 256 (n): the same eight waves
+//   2 (m) x 4 (n), each owning 64 x 64 as 2 x 2 MFMA tiles, the same four phases of now 4 MFMAs, activation half-tiles
+//   of 8 KiB (one DMA load per thread instead of two; they keep their 16 KiB slots).  It reads one fragment from LDS
+//   per MFMA instead of three per four, which is about what the LDS delivers: slower per flop than the full tile,
+//   faster than half a chip.
 #include "common.h"
 #include "elem.h"
 #include "gemm.h"
@@ -32,7 +39,7 @@
 
 namespace asrfe {
 
-constexpr int BM = 256, BN = 256, BK = 64;
+constexpr int BN = 256, BK = 64;  // (tile height: 128 * MS rows)
 constexpr int kGemmThreads = 512;
 constexpr int kHalfBytes = 128 * BK * 2;     // 16 KiB: one half-tile
 constexpr int kSlotBytes = 4 * kHalfBytes;   // A0 | A1 | B0 | B1
@@ -46,9 +53,13 @@ constexpr int kGemmLds = kRingBytes + 8 * 4096;  // + one 4 KiB epilogue slab pe
 // is refilled after this barrier while reads of it issued just before the barrier may not have returned yet;
 // they are already queued in the LDS pipeline, which serves one wave's requests in order and receives the DMA
 // data only a global-memory round trip later.
+// The five youngest half-tiles are ten loads at full height.  At half height an activation half-tile is one load and a
+// weight half-tile two, and the five youngest are, depending on the phase, three activation + two weight half-tiles (7
+// loads) or two + three (8): the wait uses 7 everywhere, which at the second kind of phase also waits for one load more
+// than needed.
 #define PHASE_SYNC(steady)                                                                         \
     do {                                                                                           \
-        if (steady) asm volatile("s_waitcnt vmcnt(10)\n\ts_barrier" ::: "memory");                \
+        if (steady) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(MS == 2 ? 10 : 7) : "memory"); \
         else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");                        \
     } while (0)
 
@@ -76,8 +87,8 @@ __device__ __forceinline__ void wave_lds_sync() {
 // 32-row slab goes through a 4 KiB wave-private LDS tile (128-byte rows, 16-byte chunk c of row r kept at
 // chunk c ^ (r & 7): conflict-free both ways) and comes back with 8 consecutive lanes holding one full
 // 128-byte line, so each global access moves whole lines.  Only wave-level ordering is needed.
-template <int EPI, bool F16>
-__device__ __forceinline__ void gemm_epilogue(const GemmParams& p, const f32x16 (&acc)[2][4], int m0, int n0, int wm, int wn,
+template <int EPI, bool F16, int MS>
+__device__ __forceinline__ void gemm_epilogue(const GemmParams& p, const f32x16 (&acc)[2][2 * MS], int m0, int n0, int wm, int wn,
                                               int lane, char* es) {
     const int l31 = lane & 31, h = lane >> 5;
     const int wr_row = l31 * 128, wr_sw = l31 & 7;   // this lane's row in the slab when writing
@@ -89,14 +100,14 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, const f32x16 
         for (int ns = 0; ns < 2; ++ns) {
             const int nb = n0 + wn * 64 + ns * 32;
 #pragma unroll
-            for (int ms = 0; ms < 4; ++ms) {
+            for (int ms = 0; ms < 2 * MS; ++ms) {
                 const f32x16 a = acc[ns][ms];
 #pragma unroll
                 for (int g = 0; g < 4; ++g)
                     *reinterpret_cast<float4*>(es + wr_row + (((2 * g + h) ^ wr_sw) << 4)) =
                         make_float4(a[4 * g], a[4 * g + 1], a[4 * g + 2], a[4 * g + 3]);
                 wave_lds_sync();
-                const int mb = m0 + wm * 128 + ms * 32;
+                const int mb = m0 + wm * (64 * MS) + ms * 32;
 #pragma unroll 2
                 for (int i = 0; i < 4; ++i) {
                     const int r = rd_row + 8 * i;
@@ -124,7 +135,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, const f32x16 
         }
     } else {
 #pragma unroll
-        for (int ms = 0; ms < 4; ++ms) {
+        for (int ms = 0; ms < 2 * MS; ++ms) {
 #pragma unroll
             for (int ns = 0; ns < 2; ++ns) {
                 const f32x16 a = acc[ns][ms];
@@ -147,7 +158,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, const f32x16 
                 }
             }
             wave_lds_sync();
-            const int mb = m0 + wm * 128 + ms * 32;
+            const int mb = m0 + wm * (64 * MS) + ms * 32;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int r = rd_row + 8 * i;
@@ -161,8 +172,9 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, const f32x16 
     }
 }
 
-template <int EPI, bool F16>
+template <int EPI, bool F16, int MS>
 __global__ __launch_bounds__(kGemmThreads) void gemm_bf16_kernel(const GemmParams p) {
+    constexpr int BM = 128 * MS;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     saturate_fp16_conversions<F16>();
     const int tid = threadIdx.x;
@@ -186,12 +198,13 @@ __global__ __launch_bounds__(kGemmThreads) void gemm_bf16_kernel(const GemmParam
     const int n_kt = n_my * nk;  // K-tiles this workgroup consumes, over all its output tiles
 
     // ---- staging: thread covers LDS slot (local row j * 64 + (tid >> 3), chunk tid & 7) of a half-tile
+    //      (an activation half-tile has 64 * MS rows: local row wm * 32 MS + r is row r of wave row wm's share)
     const int srow = tid >> 3;
     const int schunk = (tid & 7) ^ ((tid >> 4) & 7);  // source chunk that belongs in that slot
     const int wave_slot = wave * 1024;
     const char* a_tile;
     const char* w_tile;
-    uint32_t aoff[2][2], boff[2][2];  // [half][j] byte offsets from the tile base
+    uint32_t aoff[2][MS], boff[2][2];  // [half][j] byte offsets from the tile base
 #pragma unroll
     for (int hf = 0; hf < 2; ++hf)
 #pragma unroll
@@ -210,8 +223,9 @@ __global__ __launch_bounds__(kGemmThreads) void gemm_bf16_kernel(const GemmParam
 #pragma unroll
         for (int hf = 0; hf < 2; ++hf)
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                int ra_ = j * 128 + hf * 64 + srow;  // tile row behind this local row of activation half hf
+            for (int j = 0; j < MS; ++j) {
+                // tile row behind this local row of activation half hf
+                int ra_ = MS == 2 ? j * 128 + hf * 64 + srow : (srow >> 5) * 64 + hf * 32 + (srow & 31);
                 ra_ = (sm0 + ra_ < p.M) ? ra_ : (p.M - 1 - sm0);
                 aoff[hf][j] = static_cast<uint32_t>(ra_) * p.lda * 2 + schunk * 16;
             }
@@ -232,7 +246,7 @@ __global__ __launch_bounds__(kGemmThreads) void gemm_bf16_kernel(const GemmParam
         const int kb = st_kt * (BK * 2);
         if (half < 2) {
             lds_dma16(a_tile + kb, aoff[half][0], dst);
-            lds_dma16(a_tile + kb, aoff[half][1], dst + 8192);
+            if constexpr (MS == 2) lds_dma16(a_tile + kb, aoff[half][MS - 1], dst + 8192);
         } else {
             lds_dma16(w_tile + kb, boff[half - 2][0], dst);
             lds_dma16(w_tile + kb, boff[half - 2][1], dst + 8192);
@@ -245,11 +259,11 @@ __global__ __launch_bounds__(kGemmThreads) void gemm_bf16_kernel(const GemmParam
     int coff[4];
 #pragma unroll
     for (int s = 0; s < 4; ++s) coff[s] = ((2 * s + h) ^ swz) << 4;
-    const int a_row_off = (wm * 64 + l31) * 128;                   // + a * kHalfBytes + ms * 4096
+    const int a_row_off = (wm * (32 * MS) + l31) * 128;            // + a * kHalfBytes + ms * 4096
     const int b_row_off = 2 * kHalfBytes + (wn * 32 + l31) * 128;  // + b * kHalfBytes
 
     // accumulators start from the bias: register e of acc[b][*] is column n0 + wn * 64 + b * 32 + 8 (e >> 2) + 4 h + (e & 3)
-    auto init_acc = [&](f32x16 (&acc_)[2][4], int tile) {
+    auto init_acc = [&](f32x16 (&acc_)[2][2 * MS], int tile) {
         const int tn_ = tile % p.n_tiles_n;
 #pragma unroll
         for (int b = 0; b < 2; ++b) {
@@ -260,13 +274,13 @@ __global__ __launch_bounds__(kGemmThreads) void gemm_bf16_kernel(const GemmParam
                 bvec[4 * g] = t4.x; bvec[4 * g + 1] = t4.y; bvec[4 * g + 2] = t4.z; bvec[4 * g + 3] = t4.w;
             }
 #pragma unroll
-            for (int ms = 0; ms < 4; ++ms) acc_[b][ms] = bvec;
+            for (int ms = 0; ms < 2 * MS; ++ms) acc_[b][ms] = bvec;
         }
     };
 
-    u16x8 ra[2][4];    // activation fragments [ms][s] of the current A half
-    u16x8 rb[2][4];    // weight fragments [b][s]: rb[0] always holds B0, rb[1] always holds B1
-    f32x16 acc[2][4];  // [b][a * 2 + ms]
+    u16x8 ra[MS][4];        // activation fragments [ms][s] of the current A half
+    u16x8 rb[2][4];         // weight fragments [b][s]: rb[0] always holds B0, rb[1] always holds B1
+    f32x16 acc[2][2 * MS];  // [b][a * MS + ms]
     init_acc(acc, first_tile);
 
     auto read_a = [&](int a, int slot, int ms, int s) {
@@ -278,7 +292,7 @@ __global__ __launch_bounds__(kGemmThreads) void gemm_bf16_kernel(const GemmParam
             rb[b][s] = *reinterpret_cast<const u16x8*>(smem + slot * kSlotBytes + b * kHalfBytes + b_row_off + coff[s]);
     };
 
-    // One phase: 8 MFMAs of quadrant (A_, B_).  ROLL_A >= 0: refill ra with half ROLL_A of ROLL_SLOT as it is
+    // One phase: 4 MS MFMAs of quadrant (A_, B_).  ROLL_A >= 0: refill ra with half ROLL_A of ROLL_SLOT as it is
     // consumed.  FREE_B >= 0: load rb[FREE_B] (idle in this phase) from FREE_SLOT.  STAGE: issue that half of
     // the K-tile two ahead (if it exists).
 #define PHASE(A_, B_, STAGE_HALF, STAGE_SLOT, FREE_B, FREE_SLOT, ROLL_A, ROLL_SLOT, SYNC, STEADY)            \
@@ -286,8 +300,8 @@ __global__ __launch_bounds__(kGemmThreads) void gemm_bf16_kernel(const GemmParam
         if (STEADY) stage(STAGE_HALF, STAGE_SLOT);                                           \
         if (FREE_B >= 0) read_b(FREE_B < 0 ? 0 : FREE_B, FREE_SLOT);                            \
         _Pragma("unroll") for (int s = 0; s < 4; ++s) {                                                     \
-            _Pragma("unroll") for (int ms = 0; ms < 2; ++ms) {                                              \
-                acc[B_][(A_) * 2 + ms] = mfma32<F16>(rb[B_][s], ra[ms][s], acc[B_][(A_) * 2 + ms]);         \
+            _Pragma("unroll") for (int ms = 0; ms < MS; ++ms) {                                             \
+                acc[B_][(A_) * MS + ms] = mfma32<F16>(rb[B_][s], ra[ms][s], acc[B_][(A_) * MS + ms]);       \
                 if (ROLL_A >= 0) read_a(ROLL_A < 0 ? 0 : ROLL_A, ROLL_SLOT, ms, s);             \
             }                                                                                               \
         }                                                                                                   \
@@ -304,7 +318,7 @@ __global__ __launch_bounds__(kGemmThreads) void gemm_bf16_kernel(const GemmParam
 #pragma unroll
     for (int s = 0; s < 4; ++s)
 #pragma unroll
-        for (int ms = 0; ms < 2; ++ms) read_a(0, 0, ms, s);
+        for (int ms = 0; ms < MS; ++ms) read_a(0, 0, ms, s);
     read_b(0, 0);
 
     int cur_tile = first_tile;
@@ -326,7 +340,7 @@ __global__ __launch_bounds__(kGemmThreads) void gemm_bf16_kernel(const GemmParam
         kt_in_tile += 2;
         if (kt_in_tile == nk) {  // this output tile is complete: store it while the next tile's loads fly
             const int tm = cur_tile / p.n_tiles_n, tn = cur_tile - tm * p.n_tiles_n;
-            gemm_epilogue<EPI, F16>(p, acc, tm * BM, tn * BN, wm, wn, lane, smem + kRingBytes + wave * 4096);
+            gemm_epilogue<EPI, F16, MS>(p, acc, tm * BM, tn * BN, wm, wn, lane, smem + kRingBytes + wave * 4096);
             kt_in_tile = 0;
             cur_tile += wgs_of_xcd;
             if (g + 2 < n_kt) init_acc(acc, cur_tile);
@@ -338,12 +352,18 @@ __global__ __launch_bounds__(kGemmThreads) void gemm_bf16_kernel(const GemmParam
 // The dynamic-LDS limit of a kernel is a per-device attribute: asrfe_create calls this with the context's device
 // current, before any compute call can run.
 int32_t prepare_gemm(asrfe_ctx* ctx) {
-    const void* fns[6] = {reinterpret_cast<const void*>(gemm_bf16_kernel<EPI_BF16, false>),
-                          reinterpret_cast<const void*>(gemm_bf16_kernel<EPI_BF16_RELU, false>),
-                          reinterpret_cast<const void*>(gemm_bf16_kernel<EPI_F32_ADD, false>),
-                          reinterpret_cast<const void*>(gemm_bf16_kernel<EPI_BF16, true>),
-                          reinterpret_cast<const void*>(gemm_bf16_kernel<EPI_BF16_RELU, true>),
-                          reinterpret_cast<const void*>(gemm_bf16_kernel<EPI_F32_ADD, true>)};
+    const void* fns[12] = {reinterpret_cast<const void*>(gemm_bf16_kernel<EPI_BF16, false, 2>),
+                           reinterpret_cast<const void*>(gemm_bf16_kernel<EPI_BF16_RELU, false, 2>),
+                           reinterpret_cast<const void*>(gemm_bf16_kernel<EPI_F32_ADD, false, 2>),
+                           reinterpret_cast<const void*>(gemm_bf16_kernel<EPI_BF16, true, 2>),
+                           reinterpret_cast<const void*>(gemm_bf16_kernel<EPI_BF16_RELU, true, 2>),
+                           reinterpret_cast<const void*>(gemm_bf16_kernel<EPI_F32_ADD, true, 2>),
+                           reinterpret_cast<const void*>(gemm_bf16_kernel<EPI_BF16, false, 1>),
+                           reinterpret_cast<const void*>(gemm_bf16_kernel<EPI_BF16_RELU, false, 1>),
+                           reinterpret_cast<const void*>(gemm_bf16_kernel<EPI_F32_ADD, false, 1>),
+                           reinterpret_cast<const void*>(gemm_bf16_kernel<EPI_BF16, true, 1>),
+                           reinterpret_cast<const void*>(gemm_bf16_kernel<EPI_BF16_RELU, true, 1>),
+                           reinterpret_cast<const void*>(gemm_bf16_kernel<EPI_F32_ADD, true, 1>)};
     for (const void* f : fns)
         if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, kGemmLds) != hipSuccess)
             return set_err(ctx, ASRFE_ERR_HIP, "gemm: cannot raise the dynamic LDS limit to 160 KiB");
@@ -355,15 +375,25 @@ int32_t launch_gemm(asrfe_ctx* ctx, const GemmParams& pin, int epi, hipStream_t 
     if (p.M <= 0) return ASRFE_OK;
     if (p.N % BN != 0 || p.K % (2 * BK) != 0 || p.K <= 0 || p.lda % 8 != 0 || p.ldw % 8 != 0 || p.ldo % 8 != 0)
         return set_err(ctx, ASRFE_ERR_SHAPE, "gemm: N must be a multiple of 256, K of 128, leading dims of 8");
-    p.n_tiles_m = (p.M + BM - 1) / BM;
     p.n_tiles_n = p.N / BN;
+    // Half-height tiles when they still fit the chip in one round and full-height tiles would leave CUs idle
+    // (flags bits 8-9 force a height: 1 full, 2 half).
+    const int tiles_full = (p.M + 255) / 256 * p.n_tiles_n, tiles_half = (p.M + 127) / 128 * p.n_tiles_n;
+    const int force = (p.flags >> 8) & 3;
+    const bool half = force == 2 || (force == 0 && tiles_half > tiles_full && tiles_half <= ctx->num_cus);
+    p.n_tiles_m = half ? (p.M + 127) / 128 : (p.M + 255) / 256;
     const int n_tiles = p.n_tiles_m * p.n_tiles_n;
     dim3 grid(n_tiles < ctx->num_cus ? n_tiles : ctx->num_cus), block(kGemmThreads);
     const bool f16 = ctx->cfg.enc_compute_dtype == ASRFE_DT_F16;
-#define LAUNCH_GEMM(E)                                                                        \
-    do {                                                                                      \
-        if (f16) hipLaunchKernelGGL((gemm_bf16_kernel<E, true>), grid, block, kGemmLds, s, p); \
-        else hipLaunchKernelGGL((gemm_bf16_kernel<E, false>), grid, block, kGemmLds, s, p);    \
+#define LAUNCH_GEMM_H(E, MS_)                                                                       \
+    do {                                                                                            \
+        if (f16) hipLaunchKernelGGL((gemm_bf16_kernel<E, true, MS_>), grid, block, kGemmLds, s, p);  \
+        else hipLaunchKernelGGL((gemm_bf16_kernel<E, false, MS_>), grid, block, kGemmLds, s, p);     \
+    } while (0)
+#define LAUNCH_GEMM(E)                   \
+    do {                                 \
+        if (half) LAUNCH_GEMM_H(E, 1);   \
+        else LAUNCH_GEMM_H(E, 2);        \
     } while (0)
     switch (epi) {
         case EPI_BF16: LAUNCH_GEMM(EPI_BF16); break;
@@ -372,6 +402,7 @@ int32_t launch_gemm(asrfe_ctx* ctx, const GemmParams& pin, int epi, hipStream_t 
         default: return set_err(ctx, ASRFE_ERR_BAD_ARG, "gemm: bad epilogue");
     }
 #undef LAUNCH_GEMM
+#undef LAUNCH_GEMM_H
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) return set_err(ctx, ASRFE_ERR_HIP, std::string("gemm launch: ") + hipGetErrorString(e));
     return ASRFE_OK;

@@ -18,6 +18,11 @@ SHAPES = [  # name, M, N, K, epi, add16, add32
     ("out", 32000, 512, 512, 2, True, True),
     ("ffn1", 32000, 2048, 512, 1, False, False),
     ("ffn2", 32000, 512, 2048, 2, False, True),
+    # the decoder's products over 64 x 256 token rows: 128 full-height tiles for 256 CUs (flags 256 / 512 force a height)
+    ("dq", 16384, 512, 512, 0, False, False),
+    ("do", 16384, 512, 512, 2, False, True),
+    ("dw2", 16384, 512, 2048, 2, False, True),
+    ("dw1", 16384, 2048, 512, 1, False, False),
 ]
 
 
