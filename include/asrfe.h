@@ -310,7 +310,8 @@ int32_t asrfe_profile_end(asrfe_ctx* ctx, asrfe_profile* out);
  * out[M][N] = epilogue(A[M][K] * W[N][K]^T + bias), 16-bit operands in the context's enc_compute_dtype.
  * epi: 0 = 16-bit out, 1 = 16-bit out with ReLU, 2 = f32 out + add16 (16-bit, optional) + add32 (f32, optional).
  * N must be a multiple of 256 and K of 128; all pointers are device pointers.  flags bit 0 skips the stores
- * (timing experiments only). */
+ * (timing experiments only); bits 8-9 force the output tile height (1: 256 rows, 2: 128 rows; 0: the launch
+ * takes 128 rows where tiles of 256 would leave compute units idle; the result is the same bit for bit). */
 int32_t asrfe_debug_gemm(asrfe_ctx* ctx, const void* a, int32_t lda, const void* w, int32_t ldw, const float* bias,
                          int32_t m, int32_t n, int32_t k, void* out, int32_t ldo, const void* add16,
                          const float* add32, int32_t epi, int32_t flags, void* stream);

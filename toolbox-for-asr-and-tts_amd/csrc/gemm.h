@@ -25,7 +25,8 @@ struct GemmParams {
     const float* add32;     // optional f32 [M][ld32]
     int ld32;
     int n_tiles_m, n_tiles_n;  // filled by launch_gemm
-    int flags;                 // bit 0: skip the epilogue stores (timing experiments); bits 4-5: store cache policy
+    int flags;                 // bit 0: skip the epilogue stores (timing experiments); bits 4-5: store cache policy;
+                               // bits 8-9: force the tile height (1: 256 rows, 2: 128 rows; 0: launch_gemm chooses)
 };
 
 int32_t launch_gemm(asrfe_ctx* ctx, const GemmParams& p, int epi, hipStream_t s);
