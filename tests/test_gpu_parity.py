@@ -287,6 +287,34 @@ def test_encoder_one_layer_vs_oracle_various_lengths(pkg, small_rows):
 
 
 @pytest.mark.parametrize("small_rows", PLANS)
+def test_encoder_random_shapes_vs_oracle(pkg, small_rows):
+    """Seeded random batches (1-7 utterances, T' up to 330, lengths from 1 to T'), three layers so that the layers
+    hand the residual stream on in the kernels' own layout: row counts that end anywhere inside a 32-row group, a
+    128-row tile or a key tile, utterances of one frame next to full ones."""
+    rng = np.random.default_rng(20240607)
+    cfg = so.SanmConfig(num_blocks=3)
+    sd = so.make_state_dict(cfg, seed=8, dtype=torch.float32)
+    enc = pkg.SANMEncoder(num_blocks=3, small_batch_rows=small_rows)
+    enc.load_state_dict(sd)
+    sdd = {k: v.double() for k, v in sd.items()}
+    for case in range(10):
+        b = int(rng.integers(1, 8))
+        tp = int(rng.integers(1, 331))
+        lens = [int(v) for v in rng.integers(1, tp + 1, size=b)]
+        lens[int(rng.integers(0, b))] = tp
+        feats = so.synth_feats(b, tp, 560, seed=100 + case)
+        lt = torch.tensor(lens, dtype=torch.int32)
+        out, olens, _ = enc.forward(feats.cuda(), lt)
+        torch.cuda.synchronize()
+        want, wl = so.encoder_forward(feats.double(), lt, sdd, cfg)
+        assert olens.cpu().tolist() == wl.tolist()
+        err = float((out.cpu().double() - want).abs().max())
+        assert err <= ENC_TOL, (case, b, tp, lens, err)
+        for i, n in enumerate(lens):
+            assert float(out[i, n:].abs().max()) == 0.0 if n < tp else True
+
+
+@pytest.mark.parametrize("small_rows", PLANS)
 def test_encoder_50_layers_probe(pkg, small_rows):
     g = np.load(os.path.join(GOLDEN, "encoder_probe_50l.npz"))
     feats = so.synth_feats(2, 96, 560, seed=int(g["feats_seed"]))
