@@ -312,8 +312,8 @@ extern "C" int32_t asrfe_decoder_forward(asrfe_ctx* ctx, const float* enc_out, c
         DecFsmnParams fp{};
         fp.t = b.t; fp.x = b.x; fp.gamma = L.n2_g; fp.beta = L.n2_b; fp.taps = L.taps; fp.token_num = token_num;
         fp.N = n_max; fp.eps = eps;
+        fp.h = b.h;  // the LayerNorm in front of the query projection leaves the same kernel
         if ((rc = launch_dec_fsmn(ctx, fp, batch, s))) return rc;
-        if ((rc = launch_ln512(ctx, b.x, nullptr, nullptr, eps, Md, b.h, s))) return rc;
         if ((rc = gemm(ctx, b.h, 512, L.wq, 512, L.bq, Md, 512, 512, b.q, 512, nullptr, EPI_BF16, s))) return rc;
         if ((rc = gemm(ctx, mem16, 1536, L.wkv, 512, L.bkv, M, 1024, 512, b.kv, 1024, nullptr, EPI_BF16, s))) return rc;
         AttnParams a{};

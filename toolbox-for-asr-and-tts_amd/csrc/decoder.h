@@ -50,6 +50,7 @@ struct DecFsmnParams {
     const int32_t* token_num;
     int N;
     float eps;
+    uint16_t* h;            // optional [B][N][512], 16-bit: the plain LayerNorm (no scale / shift) of the updated rows
 };
 
 int32_t launch_pred_split(asrfe_ctx* ctx, const float* enc, const int32_t* lens, int B, int Tp, uint16_t* hi, uint16_t* lo, hipStream_t s);

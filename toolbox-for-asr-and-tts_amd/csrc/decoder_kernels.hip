@@ -199,9 +199,14 @@ __global__ __launch_bounds__(256) void ln_hidden_kernel(const uint16_t* __restri
 // t is the feed-forward output, LN2 the layer's norm2 (scale and shift applied here: a depth-wise convolution with
 // zero padding does not commute with a shift).  One workgroup = 16 token rows of one utterance (52 KiB of LDS: three
 // workgroups per CU): its four waves normalise the 26 rows the window touches into LDS (rows outside the utterance's
-// tokens are zero), then a thread owns two channels and slides the 11 taps down the 16 rows.
+// tokens are zero), then a thread owns two channels and slides the 11 taps down the 16 rows.  With p.h set the
+// workgroup also writes the LayerNorm of its 16 updated rows as 16-bit operands (the next product's input; its scale
+// and shift live in that product's weights): the rows go back through the LDS, a wave normalises four of them with the
+// arithmetic of ln_kernel, in its order, and no separate launch reads the residual stream again.
 constexpr int kDecFsmnRows = 16;
+template <bool F16>
 __global__ __launch_bounds__(256) void dec_fsmn_kernel(const DecFsmnParams p) {
+    saturate_fp16_conversions<F16>();
     __shared__ __attribute__((aligned(16))) float tn[(kDecFsmnRows + 10) * 512];
     const int b = blockIdx.y;
     const int r0 = blockIdx.x * kDecFsmnRows;
@@ -249,12 +254,13 @@ __global__ __launch_bounds__(256) void dec_fsmn_kernel(const DecFsmnParams p) {
 #pragma unroll
     for (int j = 0; j < 11; ++j) w[j] = reinterpret_cast<const float2*>(p.taps + j * 512)[tid];
     const float2* col = reinterpret_cast<const float2*>(tn) + tid;
+    const int nrow = p.h ? p.N : ntok;  // (the LayerNorm covers the rows past the tokens too, as its own launch did)
     float2 xin[kDecFsmnRows];
 #pragma unroll
     for (int i = 0; i < kDecFsmnRows; ++i) {
         const int r = r0 + i;
         xin[i] = make_float2(0.0f, 0.0f);
-        if (r < ntok) xin[i] = reinterpret_cast<const float2*>(p.x + (static_cast<int64_t>(b) * p.N + r) * 512)[tid];
+        if (r < nrow) xin[i] = reinterpret_cast<const float2*>(p.x + (static_cast<int64_t>(b) * p.N + r) * 512)[tid];
     }
 #pragma unroll
     for (int i = 0; i < kDecFsmnRows; ++i) {
@@ -267,7 +273,27 @@ __global__ __launch_bounds__(256) void dec_fsmn_kernel(const DecFsmnParams p) {
             acc.x = fmaf(w[j].x, v.x, acc.x);
             acc.y = fmaf(w[j].y, v.y, acc.y);
         }
-        reinterpret_cast<float2*>(p.x + (static_cast<int64_t>(b) * p.N + r) * 512)[tid] = make_float2(xin[i].x + acc.x, xin[i].y + acc.y);
+        xin[i] = make_float2(xin[i].x + acc.x, xin[i].y + acc.y);
+        reinterpret_cast<float2*>(p.x + (static_cast<int64_t>(b) * p.N + r) * 512)[tid] = xin[i];
+    }
+    if (!p.h) return;
+    __syncthreads();  // every thread is done with the normalised rows: the first 16 rows of the region take the new x
+#pragma unroll
+    for (int i = 0; i < kDecFsmnRows; ++i) reinterpret_cast<float2*>(tn + i * 512)[tid] = xin[i];
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < kDecFsmnRows / 4; ++k) {
+        const int i = wave + 4 * k, r = r0 + i;
+        if (r >= p.N) break;
+        const float4 a = reinterpret_cast<const float4*>(tn + i * 512)[lane], c = reinterpret_cast<const float4*>(tn + i * 512)[lane + 64];
+        const float mean = wave_sum(((a.x + a.y) + (a.z + a.w)) + ((c.x + c.y) + (c.z + c.w))) / 512.0f;
+        const float a0 = a.x - mean, a1 = a.y - mean, a2 = a.z - mean, a3 = a.w - mean;
+        const float c0 = c.x - mean, c1 = c.y - mean, c2 = c.z - mean, c3 = c.w - mean;
+        const float var = wave_sum(((a0 * a0 + a1 * a1) + (a2 * a2 + a3 * a3)) + ((c0 * c0 + c1 * c1) + (c2 * c2 + c3 * c3))) / 512.0f;
+        const float rstd = 1.0f / sqrtf(var + p.eps);
+        uint2* dst = reinterpret_cast<uint2*>(p.h + (static_cast<int64_t>(b) * p.N + r) * 512);
+        dst[lane] = make_uint2(pack_elem2<F16>(a0 * rstd, a1 * rstd), pack_elem2<F16>(a2 * rstd, a3 * rstd));
+        dst[lane + 64] = make_uint2(pack_elem2<F16>(c0 * rstd, c1 * rstd), pack_elem2<F16>(c2 * rstd, c3 * rstd));
     }
 }
 
@@ -379,7 +405,9 @@ int32_t launch_ln_hidden(asrfe_ctx* ctx, const uint16_t* in, uint16_t* out, int 
 
 int32_t launch_dec_fsmn(asrfe_ctx* ctx, const DecFsmnParams& p, int B, hipStream_t s) {
     if (B <= 0 || p.N <= 0) return ASRFE_OK;
-    hipLaunchKernelGGL(dec_fsmn_kernel, dim3((p.N + kDecFsmnRows - 1) / kDecFsmnRows, B), dim3(256), 0, s, p);
+    const dim3 grid((p.N + kDecFsmnRows - 1) / kDecFsmnRows, B);
+    if (ctx->cfg.enc_compute_dtype == ASRFE_DT_F16) hipLaunchKernelGGL(dec_fsmn_kernel<true>, grid, dim3(256), 0, s, p);
+    else hipLaunchKernelGGL(dec_fsmn_kernel<false>, grid, dim3(256), 0, s, p);
     DEC_CHECK_LAUNCH("dec_fsmn");
     return ASRFE_OK;
 }
