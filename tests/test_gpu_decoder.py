@@ -119,6 +119,44 @@ def test_full_size_decoder(pkg, plan):
     assert torch.equal(cut["embeds"], full["embeds"][:, :n_cut])
 
 
+@pytest.mark.parametrize("vocab", [515, 8404])
+def test_token_ids_without_logits_equal_those_with(pkg, vocab):
+    """A caller that does not ask for the logits gets its ids from the vocabulary projection's own per-strip maxima
+    (throughput plan; nothing of the projection is stored): the same ids as with the logits, for a vocabulary that ends
+    inside a strip, with an empty utterance in the batch; and with all logits of a row equal the lowest index wins."""
+    cfg = po.DecoderConfig(num_blocks=1, vocab_size=vocab)
+    sd = po.make_state_dict(cfg, seed=31)
+    g = torch.Generator().manual_seed(32)
+    mem = torch.randn(4, 90, 512, generator=g)
+    lens = torch.tensor([90, 0, 64, 17], dtype=torch.int32)
+    head = make_head(pkg, cfg, sd, 0)
+    a = head.forward(mem.cuda(), lens, return_logits=True)
+    b = head.forward(mem.cuda(), lens)
+    torch.cuda.synchronize()
+    assert "logits" not in b
+    assert torch.equal(a["token_ids"], b["token_ids"])
+    assert torch.equal(a["token_num"], b["token_num"]) and int(a["token_num"].sum()) > 0
+    # ties: a constant output layer; the last vocabulary entry alone is raised in a second run
+    sd2 = dict(sd)
+    sd2["decoder.output_layer.weight"] = torch.zeros_like(sd["decoder.output_layer.weight"])
+    sd2["decoder.output_layer.bias"] = torch.full_like(sd["decoder.output_layer.bias"], 0.25)
+    head2 = make_head(pkg, cfg, sd2, 0)
+    for with_logits in (True, False):
+        r = head2.forward(mem.cuda(), lens, return_logits=with_logits)
+        ids = r["token_ids"]
+        for k in range(4):
+            n = int(r["token_num"][k])
+            assert torch.all(ids[k, :n] == 0) and torch.all(ids[k, n:] == -1)
+    sd2["decoder.output_layer.bias"] = sd2["decoder.output_layer.bias"].clone()
+    sd2["decoder.output_layer.bias"][vocab - 1] = 0.5
+    head3 = make_head(pkg, cfg, sd2, 0)
+    for with_logits in (True, False):
+        r = head3.forward(mem.cuda(), lens, return_logits=with_logits)
+        for k in range(4):
+            n = int(r["token_num"][k])
+            assert torch.all(r["token_ids"][k, :n] == vocab - 1)
+
+
 def test_engine_to_token_ids(pkg):
     """PCM -> frontend -> encoder -> predictor -> decoder on the device; the head's result equals the oracle head run
     on the device encoder's own output (the oracle encoder's output differs by the encoder tolerance, which moves

@@ -327,6 +327,16 @@ extern "C" int32_t asrfe_decoder_forward(asrfe_ctx* ctx, const float* enc_out, c
     // closing block: feed-forward without residual, after_norm (folded into the output layer), vocabulary projection
     if ((rc = feed_forward(W.w1_last, W.b1_last, W.w2_last, W.b2_last))) return rc;
     if ((rc = launch_ln512(ctx, b.t, nullptr, nullptr, eps, Md, b.h, s))) return rc;
+    // The caller does not ask for the logits and the rows take the general GEMM: its epilogue keeps the largest value
+    // of every 64-column strip with its column instead of storing 554 MB (at 64 x 256 rows) for the arg-max to read back.
+    // The values compared are the ones the stored logits would hold, so the ids are the same.
+    if (!logits && Md > ctx->cfg.enc_small_batch_rows) {
+        GemmParams g{};
+        g.A = b.h; g.lda = 512; g.W = W.w_out; g.ldw = 512; g.bias = W.b_out; g.M = Md; g.N = W.vocab_pad; g.K = 512;
+        g.out = b.logits; g.ldo = W.vocab_pad / 64; g.n_valid = W.cfg.vocab_size;
+        if ((rc = launch_gemm(ctx, g, EPI_ARGMAX, s))) return rc;
+        return launch_argmax_pairs(ctx, b.logits, W.vocab_pad / 64, batch, n_max, token_num, token_ids, s);
+    }
     float* lg = logits ? logits : b.logits;
     if ((rc = gemm(ctx, b.h, 512, W.w_out, 512, W.b_out, Md, W.vocab_pad, 512, lg, W.vocab_pad, nullptr, EPI_F32_ADD, s))) return rc;
     return launch_argmax(ctx, lg, W.vocab_pad, W.cfg.vocab_size, batch, n_max, token_num, token_ids, s);

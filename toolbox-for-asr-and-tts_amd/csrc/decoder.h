@@ -59,6 +59,9 @@ int32_t launch_pred_alpha(asrfe_ctx* ctx, const float* conv, const float* w, flo
 int32_t launch_cif(asrfe_ctx* ctx, const CifParams& p, int B, hipStream_t s);
 int32_t launch_ln_hidden(asrfe_ctx* ctx, const uint16_t* in, uint16_t* out, int M, int width, float eps, hipStream_t s);
 int32_t launch_dec_fsmn(asrfe_ctx* ctx, const DecFsmnParams& p, int B, hipStream_t s);
+// the same from (value, column) pairs, ld per row, that the vocabulary projection's arg-max epilogue leaves
+int32_t launch_argmax_pairs(asrfe_ctx* ctx, const void* pairs, int ld, int B, int N, const int32_t* token_num, int32_t* ids,
+                            hipStream_t s);
 int32_t launch_argmax(asrfe_ctx* ctx, const float* logits, int ld, int vocab, int B, int N, const int32_t* token_num,
                       int32_t* ids, hipStream_t s);
 

@@ -341,6 +341,35 @@ __global__ __launch_bounds__(256) void argmax_kernel(const float* __restrict__ l
     if (lane == 0) ids[row] = bi;
 }
 
+// ---- arg-max from the vocabulary projection's own (value, column) pairs (one per 64-column strip): one wave per row,
+// same tie rule and same row mask as argmax_kernel
+__global__ __launch_bounds__(256) void argmax_pairs_kernel(const uint2* __restrict__ pairs, int ld, int M, int N,
+                                                           const int32_t* __restrict__ token_num, int32_t* __restrict__ ids) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const int b = row / N, r = row - b * N;
+    if (r >= token_num[b]) {
+        if (lane == 0) ids[row] = -1;
+        return;
+    }
+    const uint2* src = pairs + static_cast<int64_t>(row) * ld;
+    float best = -INFINITY;
+    int bi = 0x7fffffff;
+    for (int c = lane; c < ld; c += 64) {  // (strips in rising column order: the strict comparison keeps the lowest)
+        const uint2 q = src[c];
+        const float v = __uint_as_float(q.x);
+        if (v > best) { best = v; bi = static_cast<int>(q.y); }
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+        const float ov = __shfl_xor(best, o);
+        const int oi = __shfl_xor(bi, o);
+        if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+    }
+    if (lane == 0) ids[row] = bi;
+}
+
 // ---- launchers ----------------------------------------------------------------------------------------------------
 #define DEC_CHECK_LAUNCH(who)                                                                                         \
     do {                                                                                                              \
@@ -418,6 +447,16 @@ int32_t launch_argmax(asrfe_ctx* ctx, const float* logits, int ld, int vocab, in
     if (M <= 0) return ASRFE_OK;
     hipLaunchKernelGGL(argmax_kernel, dim3((M + 3) / 4), dim3(256), 0, s, logits, ld, vocab, M, N, token_num, ids);
     DEC_CHECK_LAUNCH("argmax");
+    return ASRFE_OK;
+}
+
+int32_t launch_argmax_pairs(asrfe_ctx* ctx, const void* pairs, int ld, int B, int N, const int32_t* token_num, int32_t* ids,
+                            hipStream_t s) {
+    const int M = B * N;
+    if (M <= 0) return ASRFE_OK;
+    hipLaunchKernelGGL(argmax_pairs_kernel, dim3((M + 3) / 4), dim3(256), 0, s, static_cast<const uint2*>(pairs), ld, M, N,
+                       token_num, ids);
+    DEC_CHECK_LAUNCH("argmax_pairs");
     return ASRFE_OK;
 }
 

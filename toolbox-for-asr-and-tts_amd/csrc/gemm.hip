@@ -95,6 +95,34 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, const f32x16 
     const int rd_row = lane >> 3, rd_c = lane & 7;   // row (+ 8 i) and chunk when reading back
     const bool live = !(p.flags & 1);
     const int policy = (p.flags >> 4) & 3;
+    if constexpr (EPI == EPI_ARGMAX) {
+        // a lane meets its 32 columns of the wave's 64-column strip in rising order (register e of tile ns is column
+        // 32 ns + 8 (e >> 2) + 4 h + (e & 3)), so the strict comparison keeps the lowest column of equal values; the
+        // other 32 columns of the row sit in lane ^ 32
+        const int nb = n0 + wn * 64 + 4 * h;
+        const int nv = p.n_valid > 0 ? p.n_valid : p.N;
+        uint2* pairs = reinterpret_cast<uint2*>(p.out);
+#pragma unroll
+        for (int ms = 0; ms < 2 * MS; ++ms) {
+            float best = -INFINITY;
+            int bi = 0x7fffffff;
+#pragma unroll
+            for (int ns = 0; ns < 2; ++ns)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int n = nb + ns * 32 + 8 * (e >> 2) + (e & 3);
+                    const float v = acc[ns][ms][e];
+                    if (n < nv && v > best) { best = v; bi = n; }
+                }
+            const float ov = __shfl_xor(best, 32);
+            const int oi = __shfl_xor(bi, 32);
+            if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+            const int m = m0 + wm * (64 * MS) + ms * 32 + l31;
+            if (h == 0 && m < p.M && live)
+                pairs[static_cast<int64_t>(m) * p.ldo + (n0 >> 6) + wn] = make_uint2(__float_as_uint(best), static_cast<uint32_t>(bi));
+        }
+        return;
+    }
     if constexpr (EPI == EPI_F32_ADD) {
 #pragma unroll
         for (int ns = 0; ns < 2; ++ns) {
@@ -352,7 +380,11 @@ __global__ __launch_bounds__(kGemmThreads) void gemm_bf16_kernel(const GemmParam
 // The dynamic-LDS limit of a kernel is a per-device attribute: asrfe_create calls this with the context's device
 // current, before any compute call can run.
 int32_t prepare_gemm(asrfe_ctx* ctx) {
-    const void* fns[12] = {reinterpret_cast<const void*>(gemm_bf16_kernel<EPI_BF16, false, 2>),
+    const void* fns[16] = {reinterpret_cast<const void*>(gemm_bf16_kernel<EPI_ARGMAX, false, 2>),
+                           reinterpret_cast<const void*>(gemm_bf16_kernel<EPI_ARGMAX, true, 2>),
+                           reinterpret_cast<const void*>(gemm_bf16_kernel<EPI_ARGMAX, false, 1>),
+                           reinterpret_cast<const void*>(gemm_bf16_kernel<EPI_ARGMAX, true, 1>),
+                           reinterpret_cast<const void*>(gemm_bf16_kernel<EPI_BF16, false, 2>),
                            reinterpret_cast<const void*>(gemm_bf16_kernel<EPI_BF16_RELU, false, 2>),
                            reinterpret_cast<const void*>(gemm_bf16_kernel<EPI_F32_ADD, false, 2>),
                            reinterpret_cast<const void*>(gemm_bf16_kernel<EPI_BF16, true, 2>),
@@ -373,8 +405,9 @@ int32_t prepare_gemm(asrfe_ctx* ctx) {
 int32_t launch_gemm(asrfe_ctx* ctx, const GemmParams& pin, int epi, hipStream_t s) {
     GemmParams p = pin;
     if (p.M <= 0) return ASRFE_OK;
-    if (p.N % BN != 0 || p.K % (2 * BK) != 0 || p.K <= 0 || p.lda % 8 != 0 || p.ldw % 8 != 0 || p.ldo % 8 != 0)
+    if (p.N % BN != 0 || p.K % (2 * BK) != 0 || p.K <= 0 || p.lda % 8 != 0 || p.ldw % 8 != 0 || (p.ldo % 8 != 0 && epi != EPI_ARGMAX))
         return set_err(ctx, ASRFE_ERR_SHAPE, "gemm: N must be a multiple of 256, K of 128, leading dims of 8");
+    if (epi == EPI_ARGMAX && p.ldo < p.N / 64) return set_err(ctx, ASRFE_ERR_SHAPE, "gemm: a row of the arg-max output holds N / 64 pairs");
     p.n_tiles_n = p.N / BN;
     // Half-height tiles when they still fit the chip in one round and full-height tiles would leave CUs idle
     // (flags bits 8-9 force a height: 1 full, 2 half).
@@ -399,6 +432,7 @@ int32_t launch_gemm(asrfe_ctx* ctx, const GemmParams& pin, int epi, hipStream_t 
         case EPI_BF16: LAUNCH_GEMM(EPI_BF16); break;
         case EPI_BF16_RELU: LAUNCH_GEMM(EPI_BF16_RELU); break;
         case EPI_F32_ADD: LAUNCH_GEMM(EPI_F32_ADD); break;
+        case EPI_ARGMAX: LAUNCH_GEMM(EPI_ARGMAX); break;
         default: return set_err(ctx, ASRFE_ERR_BAD_ARG, "gemm: bad epilogue");
     }
 #undef LAUNCH_GEMM
