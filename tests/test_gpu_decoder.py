@@ -136,6 +136,17 @@ def test_token_ids_without_logits_equal_those_with(pkg, vocab):
     assert "logits" not in b
     assert torch.equal(a["token_ids"], b["token_ids"])
     assert torch.equal(a["token_num"], b["token_num"]) and int(a["token_num"].sum()) > 0
+    if vocab == 8404:  # enough token rows for the projection to take its full-height tiles (more than 256 half-height ones)
+        mem_l = torch.randn(12, 240, 512, generator=g)
+        lens_l = torch.tensor([240, 200, 240, 90, 240, 1, 240, 177, 240, 240, 64, 240], dtype=torch.int32)
+        al = head.forward(mem_l.cuda(), lens_l, return_logits=True)
+        bl = head.forward(mem_l.cuda(), lens_l)
+        torch.cuda.synchronize()
+        rows = al["token_ids"].shape[0] * al["token_ids"].shape[1]
+        assert (rows + 127) // 128 * 33 > 256, rows
+        assert torch.equal(al["token_ids"], bl["token_ids"])
+        assert torch.equal(al["token_ids"][al["token_ids"] >= 0].long(),
+                           al["logits"].argmax(-1)[al["token_ids"] >= 0])
     # ties: a constant output layer; the last vocabulary entry alone is raised in a second run
     sd2 = dict(sd)
     sd2["decoder.output_layer.weight"] = torch.zeros_like(sd["decoder.output_layer.weight"])
