@@ -873,14 +873,10 @@ def test_gemm_kernel_both_tile_heights_vs_fp64(pkg, height):
         assert torch.equal(outs[0], outs[1])
 
 
-@pytest.mark.parametrize("pingpong", ["0", "1"])
-def test_attention_fsmn_kernel_vs_fp64(pkg, monkeypatch, pingpong):
+def test_attention_fsmn_kernel_vs_fp64(pkg):
     """The attention + FSMN kernel on its own (debug hook) against an fp64 evaluation of the same 16-bit inputs:
-    ragged lengths, a length below the FSMN half-width, T' around the 64-key and 128- / 256-query tile edges.  Once with
-    the default kernel (128 query rows per workgroup) and once with ASRFE_ATTN_PINGPONG=1, under which query axes of
-    more than 128 rows take the 256-row kernel whose wave groups alternate on the matrix pipe."""
+    ragged lengths, a length below the FSMN half-width, T' around the 64-key and 128-query tile edges."""
     import ctypes as C
-    monkeypatch.setenv("ASRFE_ATTN_PINGPONG", pingpong)
     cfg = so.SanmConfig(num_blocks=1)
     sd = so.make_state_dict(cfg, seed=2, dtype=torch.float32)
     gen = torch.Generator().manual_seed(3)

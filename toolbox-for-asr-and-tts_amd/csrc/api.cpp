@@ -173,8 +173,6 @@ extern "C" int32_t asrfe_create(const asrfe_config* cfg, asrfe_ctx** out) {
         ctx->separate_qkv = e && e[0] == '1';
         e = std::getenv("ASRFE_ROW_MAJOR_X");
         ctx->row_major_x = e && e[0] == '1';
-        e = std::getenv("ASRFE_ATTN_PINGPONG");
-        ctx->attn_pingpong = e && e[0] == '1';
     }
     // the latency plan's second feed-forward product takes linear_units in 512-deep steps up to 3072
     ctx->small_rows = (cfg->enc_linear_units % 512 == 0 && cfg->enc_linear_units <= 3072 && !ctx->unfused_ffn) ? cfg->enc_small_batch_rows : 0;
@@ -318,7 +316,7 @@ extern "C" int32_t asrfe_create(const asrfe_config* cfg, asrfe_ctx** out) {
     if ((rc = upload(ctx, inv, &ctx->pe_inv))) return fail(rc);
 
     // per-device kernel attributes (dynamic LDS above 64 KiB), set here so that no compute call ever has to
-    if ((rc = prepare_gemm(ctx)) || (rc = prepare_post_attn(ctx)) || (rc = prepare_attention_pp(ctx)) || (rc = prepare_static_scratch(ctx)))
+    if ((rc = prepare_gemm(ctx)) || (rc = prepare_post_attn(ctx)) || (rc = prepare_static_scratch(ctx)))
         return fail(rc);
 
     *out = ctx;

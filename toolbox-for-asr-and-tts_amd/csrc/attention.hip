@@ -391,11 +391,6 @@ int32_t launch_attention(asrfe_ctx* ctx, const AttnParams& p, hipStream_t s) {
     // (the kernel's running 32-bit load offsets run up to two tiles past the last row before they are clamped)
     if ((static_cast<int64_t>(p.Tk) + 128) * p.ld_kv * 2 >= (int64_t{1} << 32))
         return set_err(ctx, ASRFE_ERR_SHAPE, "attention: one utterance's key / value rows must stay below 4 GiB");
-#ifdef ASRFE_ATTN_TIMING
-    if (ctx->attn_pingpong && p.Tq > 128 && (!p.flags || (p.flags & 1024))) return launch_attention_pp(ctx, p, s);
-#else
-    if (ctx->attn_pingpong && p.Tq > 128 && !p.flags) return launch_attention_pp(ctx, p, s);
-#endif
     AttnParams q = p;
     q.n_qtiles = (p.Tq + 127) / 128;
     dim3 grid(q.n_qtiles * 4 * p.B);

@@ -85,7 +85,6 @@ struct asrfe_ctx {
     bool unfused_ffn;  // ASRFE_UNFUSED_FFN=1 in the environment: LayerNorm + two GEMM launches instead of the fused kernel
     bool separate_qkv;  // ASRFE_SEPARATE_QKV=1: every layer launches its own QKV projection
     bool row_major_x;   // ASRFE_ROW_MAJOR_X=1: the residual stream stays row-major between post-attention launches
-    bool attn_pingpong; // ASRFE_ATTN_PINGPONG=1: query axes of more than 128 rows take the 256-row attention kernel
     int small_rows;     // encoder calls of at most this many rows take the latency plan (0: never)
     std::vector<asrfe::LayerWeights> layers;
     float* after_g;

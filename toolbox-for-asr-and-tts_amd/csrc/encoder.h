@@ -33,11 +33,6 @@ inline AttnParams attn_self(const uint16_t* qkv, int ld, int B, int Tp, const in
     return a;
 }
 int32_t launch_attention(asrfe_ctx* ctx, const AttnParams& p, hipStream_t s);
-// the same arithmetic for query axes of more than 128 rows: 256-row workgroups of eight waves whose two halves take
-// turns on the matrix pipe (attention_pp.hip); launch_attention picks it under ASRFE_ATTN_PINGPONG=1 (its key loop is
-// a quarter faster, the whole launch is not: see the file's header)
-int32_t launch_attention_pp(asrfe_ctx* ctx, const AttnParams& p, hipStream_t s);
-int32_t prepare_attention_pp(asrfe_ctx* ctx);  // per-device kernel attributes; called by asrfe_create
 
 // pe[t][i] = sin((t+1) inv[i]) for i < D/2, cos((t+1) inv[i - D/2]) otherwise
 int32_t launch_pe_table(asrfe_ctx* ctx, const float* inv, int Tp, int D, float* pe, hipStream_t s);
