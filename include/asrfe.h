@@ -199,11 +199,20 @@ int32_t asrfe_cif_predictor(asrfe_ctx* ctx, const float* enc_out, const int32_t*
                             int32_t n_max, float* embeds, int32_t* token_num, float* alphas_out, void* workspace,
                             int64_t workspace_bytes, void* stream);
 
+/* Token time stamps: alphas [B, tp + 1] float32 as asrfe_cif_predictor leaves them in alphas_out (tail weight in place)
+ * -> fire_frames [B, n_max] int32, the frame at which token n fires (the predictor's integrate-and-fire recurrence on its
+ * own), -1 behind an utterance's fires.  A frame is lfr_n * frame_shift samples (60 ms), so token n spans
+ * (fire_frames[n - 1], fire_frames[n]] * 60 ms: what the reference reads as "start" / "end" of a sentence
+ * (voice-service/app/services/voice_interface.py:2064-2067, 2124-2126). */
+int32_t asrfe_cif_fire_frames(asrfe_ctx* ctx, const float* alphas, int32_t batch, int32_t tp, int32_t n_max,
+                              int32_t* fire_frames, void* stream);
+
 /* ParaformerSANMDecoder.forward + arg-max: memory = enc_out [B, tp, 512] float32 with lens [B], embeds [B, n_max, 512]
  * and token_num [B] as asrfe_cif_predictor leaves them -> token_ids [B, n_max] int32 (arg-max over the vocabulary for
- * rows < token_num[b], -1 behind them; sos / eos / blank are left in: dropping them is the host's one-line filter) and
- * optionally logits [B * n_max, asrfe_decoder_logits_stride] float32 (columns >= vocab_size are padding).  Must run on
- * the same workspace right behind asrfe_cif_predictor (it reuses the 16-bit copy of enc_out that call leaves there). */
+ * rows < token_num[b], -1 behind them, 0 for a row whose logits have no maximum: all NaN or all -inf; sos / eos / blank
+ * are left in: dropping them is the host's one-line filter) and optionally logits [B * n_max,
+ * asrfe_decoder_logits_stride] float32 (columns >= vocab_size are padding).  The call builds its own 16-bit copy of
+ * enc_out (16-byte aligned): any workspace of asrfe_decoder_workspace_bytes will do, it need not be the predictor's. */
 int32_t asrfe_decoder_forward(asrfe_ctx* ctx, const float* enc_out, const int32_t* lens, int32_t batch, int32_t tp,
                               const float* embeds, const int32_t* token_num, int32_t n_max, int32_t* token_ids,
                               float* logits, void* workspace, int64_t workspace_bytes, void* stream);

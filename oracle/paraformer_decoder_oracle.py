@@ -165,6 +165,30 @@ def cif(hidden, alphas, threshold: float):
     return emb, fires, torch.tensor(counts, dtype=torch.int32)
 
 
+def cif_fire_frames(alphas, threshold: float, n_max: int, dtype=torch.float32):
+    """The frame at which each token fires, from the integrate-and-fire recurrence of ``cif`` alone (float32 by default:
+    the arithmetic the device runs): alphas (B, T + 1) with the tail weight in place -> (B, n_max) int32, frame index of
+    token n's fire, -1 behind an utterance's fires.  With LFR frames of lfr_n * frame_shift = 60 ms a token spans
+    (fire[n - 1], fire[n]] * 60 ms: the token time stamps the reference's pipeline reports per sentence
+    (/root/reference/voice-service/app/services/voice_interface.py:2064-2067, 2124-2126)."""
+    a = alphas.to(dtype)
+    b, t = a.shape
+    out = torch.full((b, n_max), -1, dtype=torch.int32)
+    one = torch.ones((), dtype=dtype)
+    thr = torch.tensor(threshold, dtype=dtype)
+    for k in range(b):
+        integrate = torch.zeros((), dtype=dtype)
+        n = 0
+        for i in range(t):
+            integrate = integrate + a[k, i]
+            if integrate >= thr:
+                integrate = integrate - one
+                if n < n_max:
+                    out[k, n] = i
+                n += 1
+    return out
+
+
 def predictor_forward(hidden, lens, sd, cfg: DecoderConfig):
     """-> (acoustic_embeds (B, N, 512), token_num (B,) int32, alphas (B, T + 1), fire counts (B,)).
     N = the largest token_num of the batch, as Paraformer crops it; token_num = floor(sum of alphas incl. the tail)."""

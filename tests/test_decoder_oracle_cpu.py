@@ -126,3 +126,26 @@ def test_decoder_fixture():
         n = int(tn[k])
         assert np.allclose(logits[k, :n].numpy(), g["logits"][k, :n], atol=1e-5)
         assert ids[k] == [t for t in g["ids"][k, :n].tolist() if t not in (0, 1, 2)]
+
+
+def test_fire_frames_are_where_the_integrator_crosses_the_threshold():
+    """cif_fire_frames restates the recurrence of cif on its own: its frames are the positions where cif's running sum
+    reaches the threshold, and a hand-made sequence fires where it must."""
+    cfg = po.DecoderConfig(num_blocks=1, vocab_size=50)
+    sd = {k: v.double() for k, v in po.make_state_dict(cfg, seed=5).items()}
+    g = torch.Generator().manual_seed(6)
+    hidden = torch.randn(3, 40, 512, generator=g, dtype=torch.float64)
+    lens = torch.tensor([40, 17, 0], dtype=torch.int32)
+    _, token_num, alphas, counts = po.predictor_forward(hidden, lens, sd, cfg)
+    ff = po.cif_fire_frames(alphas, cfg.threshold, 41, dtype=torch.float64)
+    mask = (torch.arange(40)[None, :] < lens[:, None]).double()
+    h, a, _ = po.tail_process(hidden * mask[:, :, None], po.predictor_alphas(hidden, lens, sd, cfg), lens, cfg)
+    _, fires, _ = po.cif(h, a, cfg.threshold)
+    for k in range(3):
+        want = torch.nonzero(fires[k] >= cfg.threshold).reshape(-1).tolist()
+        got = [int(v) for v in ff[k] if int(v) >= 0]
+        assert got == want and len(got) == int(counts[k])
+        assert all(int(v) == -1 for v in ff[k, len(got):])
+    hand = torch.tensor([[0.5, 0.6, 0.0, 0.9, 0.2, 1.0, 0.45]])  # sums 0.5 1.1| 0.1 1.0| 0.2 1.2| 0.65
+    assert po.cif_fire_frames(hand, 1.0, 4).tolist() == [[1, 3, 5, -1]]
+    assert po.cif_fire_frames(hand, 1.0, 2).tolist() == [[1, 3]]

@@ -190,9 +190,18 @@ def test_engine_to_token_ids(pkg):
     torch.cuda.synchronize()
     want_ids, _, want_tn, _ = po.recognize(out.cpu().double(), olens.cpu(), {k: v.double() for k, v in sd.items()}, cfg)
     assert [len(i) for i in ids] == [len(i) for i in want_ids]
-    agree = sum(a == b for x, y in zip(ids, want_ids) for a, b in zip(x, y))
-    total = sum(len(x) for x in want_ids)
-    assert total > 0 and agree >= 0.9 * total, (agree, total)   # random-weight logits are nearly flat: near-ties may differ
+    # every token whose best logit leads the runner-up by more than twice the logit tolerance in the oracle must come
+    # out the same (random-weight logits are nearly flat, so some tokens are near-ties: those may differ, and say nothing)
+    _, want_logits, _, _ = po.recognize(out.cpu().double(), olens.cpu(), {k: v.double() for k, v in sd.items()}, cfg)
+    r = head.forward(out, olens)
+    n_sure = 0
+    for k in range(2):
+        n = int(want_tn[k])
+        top2 = want_logits[k, :n].topk(2, dim=-1).values
+        sure = (top2[:, 0] - top2[:, 1]) > 2 * LOGIT_TOL
+        n_sure += int(sure.sum())
+        assert torch.equal(r["token_ids"][k, :n].cpu()[sure], want_logits[k, :n].argmax(-1)[sure].to(torch.int32))
+    assert n_sure >= 10
     # with a token list the ids become text
     head.token_list = [f"t{i}" if i % 3 else chr(0x4E00 + i) for i in range(300)]
     texts = head.recognize(out, olens)
@@ -252,3 +261,93 @@ def test_http_route_returns_the_heads_text(pkg):
     client = TestClient(svc.create_app(eng, head=head))
     r = client.post("/api/v1/voice/asr", json={"audio_data": base64.b64encode(buf.getvalue()).decode(), "diagnosis_session_id": "t"})
     assert r.status_code == 200 and r.json() == {"text": want, "success": True, "message": None, "sample_id": None}
+
+
+def _raw_calls(pkg, head, mem, lens, n_max, ws_pred, ws_dec, embeds_override=None):
+    """asrfe_cif_predictor and asrfe_decoder_forward through the C ABI with a workspace each."""
+    import ctypes as C
+    ctx = head.ctx
+    b, tp, _ = mem.shape
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    embeds = torch.empty((b, n_max, 512), dtype=torch.float32, device="cuda")
+    token_num = torch.zeros((b,), dtype=torch.int32, device="cuda")
+    ids = torch.full((b, n_max), -7, dtype=torch.int32, device="cuda")
+    alphas = torch.empty((b, tp + 1), dtype=torch.float32, device="cuda")
+    ctx.check(ctx.lib.asrfe_cif_predictor(ctx.handle, mem.data_ptr(), lens.data_ptr(), b, tp, n_max, embeds.data_ptr(),
+                                          token_num.data_ptr(), alphas.data_ptr(), ws_pred.data_ptr(), ws_pred.numel(), st))
+    if embeds_override is not None:
+        embeds = embeds_override(embeds)
+    ctx.check(ctx.lib.asrfe_decoder_forward(ctx.handle, mem.data_ptr(), lens.data_ptr(), b, tp, embeds.data_ptr(),
+                                            token_num.data_ptr(), n_max, ids.data_ptr(), None, ws_dec.data_ptr(),
+                                            ws_dec.numel(), st))
+    torch.cuda.synchronize()
+    return ids, token_num, alphas
+
+
+@pytest.mark.parametrize("plan", PLANS)
+def test_decoder_forward_needs_nothing_from_the_predictors_workspace(pkg, plan):
+    """asrfe_decoder_forward builds its own 16-bit copy of the encoder frames: run on a workspace of its own that is full
+    of NaN patterns it returns the ids of the call that shares the predictor's workspace."""
+    cfg = po.DecoderConfig(num_blocks=2, vocab_size=300)
+    sd = po.make_state_dict(cfg, seed=41)
+    head = make_head(pkg, cfg, sd, plan)
+    g = torch.Generator().manual_seed(42)
+    mem = torch.randn(3, 70, 512, generator=g).cuda()
+    lens = torch.tensor([70, 33, 64], dtype=torch.int32, device="cuda")
+    n_max = 71
+    nbytes = head.workspace_bytes(3, 70, n_max)
+    ws_a = torch.zeros(nbytes, dtype=torch.uint8, device="cuda")
+    ws_b = torch.full((nbytes,), 0xFF, dtype=torch.uint8, device="cuda")   # 0xFFFF...: NaN as fp16, bf16 and f32
+    same, tn, _ = _raw_calls(pkg, head, mem, lens, n_max, ws_a, ws_a)
+    other, tn2, _ = _raw_calls(pkg, head, mem, lens, n_max, ws_a, ws_b)
+    assert torch.equal(tn, tn2) and int(tn.sum()) > 10
+    assert torch.equal(same, other)
+    assert int((same >= 0).sum()) == int(tn.sum())
+
+
+def test_a_row_without_a_maximum_reports_a_vocabulary_index(pkg):
+    """Logits at the bottom of the float range (an output bias of -inf) have no entry above the arg-max's starting
+    value: the id of such a row is 0 (blank), never a number outside the vocabulary, on both launch plans, with and
+    without stored logits.  (NaN embeddings do not reach
+    the logits: the closing block has no residual path and its ReLU returns 0 for a NaN.)"""
+    cfg = po.DecoderConfig(num_blocks=1, vocab_size=300)
+    sd = po.make_state_dict(cfg, seed=43)
+    sd["decoder.output_layer.bias"] = torch.full_like(sd["decoder.output_layer.bias"], float("-inf"))
+    g = torch.Generator().manual_seed(44)
+    mem = torch.randn(2, 60, 512, generator=g).cuda()
+    lens = torch.tensor([60, 41], dtype=torch.int32)
+    for plan in PLANS:
+        head = make_head(pkg, cfg, sd, plan)
+        for with_logits in (False, True):
+            r = head.forward(mem, lens, return_logits=with_logits)
+            torch.cuda.synchronize()
+            for k in range(2):
+                n = int(r["token_num"][k])
+                assert n > 3 and torch.all(r["token_ids"][k, :n] == 0) and torch.all(r["token_ids"][k, n:] == -1)
+            if with_logits:
+                assert float(r["logits"][0, 0].max()) < -3e38     # (the loader keeps the bias finite: -FLT_MAX)
+            assert head.clean_ids(r["token_ids"][0].cpu().tolist(), 300) == []
+
+
+def test_fire_frames_equal_the_oracles(pkg):
+    """asrfe_cif_fire_frames on the predictor's own alphas: the frames equal those of the float32 recurrence on the same
+    alphas (exact: the same additions in the same order), one fire per token, rising, inside the utterance (the tail
+    weight may fire at position lens[b])."""
+    cfg = po.DecoderConfig(num_blocks=1, vocab_size=300)
+    sd = po.make_state_dict(cfg, seed=45)
+    head = make_head(pkg, cfg, sd)
+    g = torch.Generator().manual_seed(46)
+    mem = torch.randn(4, 130, 512, generator=g)
+    lens = torch.tensor([130, 64, 0, 97], dtype=torch.int32)
+    r = head.forward(mem.cuda(), lens, return_alphas=True, return_fire_frames=True)
+    torch.cuda.synchronize()
+    fires = r["fire_frames"].cpu()
+    want = po.cif_fire_frames(r["alphas"].cpu(), cfg.threshold, fires.shape[1])
+    assert torch.equal(fires, want)
+    for k in range(4):
+        n = int(r["token_num"][k])
+        f = fires[k][fires[k] >= 0].tolist()
+        assert len(f) >= n and f == sorted(set(f)) and all(0 <= v <= int(lens[k]) for v in f)
+    # a smaller n_max keeps the first fires
+    cut = head.forward(mem.cuda(), lens, n_max=5, return_fire_frames=True)["fire_frames"].cpu()
+    assert torch.equal(cut, fires[:, :5])

@@ -79,3 +79,38 @@ def test_input_conversion(md, tmp_path):
         wf.writeframes(pcm.tobytes())
     with pytest.raises(ValueError, match="16 kHz"):
         md.AutoModel._to_int16(str(wav))
+
+
+def test_float_input_stays_float(md):
+    x = np.array([0.0, 0.25, -1.0, 0.123456], dtype=np.float64)
+    got = md.AutoModel._to_pcm(x)
+    assert got.dtype == np.float32 and np.array_equal(got, x.astype(np.float32))
+    i = np.array([3, -4], dtype=np.int16)
+    assert md.AutoModel._to_pcm(i) is i
+    assert md.AutoModel._to_pcm(torch.tensor([[0.5], [0.25]])).tolist() == [0.5, 0.25]
+
+
+def test_decoder_variants_that_are_not_built_are_refused(md, tmp_path):
+    ref = write_model_dir(str(tmp_path / "m"))
+    cfg, sd = ref["config"], ref["state_dict"]
+    md.check_decoder_config(cfg, sd)                                   # the directory as written is fine
+    md.check_decoder_config(dict(cfg, predictor="CifPredictorV3"), sd)
+    bad = dict(cfg, decoder_conf=dict(cfg["decoder_conf"], att_layer_num=1))
+    with pytest.raises(ValueError, match="att_layer_num"):
+        md.check_decoder_config(bad, sd)
+    with pytest.raises(ValueError, match="decoders2"):
+        md.check_decoder_config(cfg, dict(sd, **{"decoder.decoders2.0.norm1.weight": torch.zeros(512)}))
+    with pytest.raises(ValueError, match="sanm_shfit"):
+        md.check_decoder_config(dict(cfg, decoder_conf=dict(cfg["decoder_conf"], sanm_shfit=5)), sd)
+    with pytest.raises(ValueError, match="predictor"):
+        md.check_decoder_config(dict(cfg, predictor="CifPredictor"), sd)
+
+
+def test_token_spans_follow_the_fires():
+    from toolbox_for_asr_and_tts_amd.decoder import ParaformerHead
+    #        sos  tok  blank tok  eos  pad
+    ids = [1, 17, 0, 250, 2, -1]
+    fires = [0, 3, 4, 9, 12, -1]
+    assert ParaformerHead.clean_ids(ids, 300) == [17, 250]
+    assert ParaformerHead.token_spans(ids, fires, 300) == [[60, 240], [300, 600]]
+    assert ParaformerHead.clean_ids([5, 0x7fffffff, 299], 300) == [5, 299]    # not a vocabulary index: dropped

@@ -144,6 +144,7 @@ SIGNATURES = {
     "asrfe_decoder_logits_stride": (C.c_int32, [C.c_void_p]),
     "asrfe_cif_predictor": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p,
                                         C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
+    "asrfe_cif_fire_frames": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
     "asrfe_decoder_forward": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,
                                           C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     "asrfe_default_vocoder_config": (C.c_int32, [C.POINTER(VocoderConfig)]),

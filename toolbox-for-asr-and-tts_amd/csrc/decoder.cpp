@@ -189,7 +189,7 @@ struct DecBuffers {
     uint16_t* g;      // [Md][ff]
     uint16_t* q;      // [Md][512]
     uint16_t* att;    // [Md][512]
-    float* logits;    // [Md][vocab_pad]
+    float* logits;    // [Md][vocab_pad / 64] (value, column) pairs; [Md][vocab_pad] f32 when Md takes the latency plan
     int64_t bytes;
 };
 
@@ -216,7 +216,10 @@ DecBuffers dec_carve(const asrfe_ctx* ctx, void* ws, int B, int Tp, int n_max) {
     b.g = reinterpret_cast<uint16_t*>(take(Md * ff * 2));
     b.q = reinterpret_cast<uint16_t*>(take(Md * 512 * 2));
     b.att = reinterpret_cast<uint16_t*>(take(Md * 512 * 2));
-    b.logits = reinterpret_cast<float*>(take(Md * ctx->dec->vocab_pad * 4));
+    // without a logits buffer of the caller's the vocabulary projection keeps one (value, column) pair per 64-column
+    // strip for the arg-max; only calls small enough for the latency plan store whole rows here
+    const int64_t small = ctx->cfg.enc_small_batch_rows;
+    b.logits = reinterpret_cast<float*>(take(Md > small ? Md * (ctx->dec->vocab_pad / 64) * 8 : Md * ctx->dec->vocab_pad * 4));
     b.bytes = off;
     return b;
 }
@@ -281,6 +284,18 @@ extern "C" int32_t asrfe_cif_predictor(asrfe_ctx* ctx, const float* enc_out, con
     return launch_cif(ctx, c, batch, s);
 }
 
+extern "C" int32_t asrfe_cif_fire_frames(asrfe_ctx* ctx, const float* alphas, int32_t batch, int32_t tp, int32_t n_max,
+                                         int32_t* fire_frames, void* stream) {
+    if (!ctx) return ASRFE_ERR_BAD_ARG;
+    if (!ctx->dec) return set_err(ctx, ASRFE_ERR_NOT_LOADED, "asrfe_cif_fire_frames: decoder weights not loaded");
+    if (batch < 0 || batch > 16384 || tp < 0 || tp > 8192 || n_max < 1 || n_max > 8193)
+        return set_err(ctx, ASRFE_ERR_SHAPE, "asrfe_cif_fire_frames: batch in 0..16384, tp in 0..8192, n_max in 1..8193");
+    if (batch == 0) return ASRFE_OK;
+    if (!alphas || !fire_frames) return set_err(ctx, ASRFE_ERR_BAD_ARG, "asrfe_cif_fire_frames: null argument");
+    return launch_cif_fire_frames(ctx, alphas, batch, tp, n_max, ctx->dec->cfg.threshold, fire_frames,
+                                  static_cast<hipStream_t>(stream));
+}
+
 extern "C" int32_t asrfe_decoder_forward(asrfe_ctx* ctx, const float* enc_out, const int32_t* lens, int32_t batch, int32_t tp,
                                          const float* embeds, const int32_t* token_num, int32_t n_max, int32_t* token_ids,
                                          float* logits, void* workspace, int64_t workspace_bytes, void* stream) {
@@ -288,15 +303,20 @@ extern "C" int32_t asrfe_decoder_forward(asrfe_ctx* ctx, const float* enc_out, c
     int32_t rc = check_common(ctx, "asrfe_decoder_forward", batch, tp, n_max, workspace, workspace_bytes);
     if (rc || batch == 0 || tp == 0) return rc;
     if (!enc_out || !lens || !embeds || !token_num || !token_ids) return set_err(ctx, ASRFE_ERR_BAD_ARG, "asrfe_decoder_forward: null argument");
-    if (reinterpret_cast<uintptr_t>(embeds) % 16 != 0 || (logits && reinterpret_cast<uintptr_t>(logits) % 16 != 0))
-        return set_err(ctx, ASRFE_ERR_BAD_ARG, "asrfe_decoder_forward: embeds / logits must be 16-byte aligned");
+    if (reinterpret_cast<uintptr_t>(embeds) % 16 != 0 || reinterpret_cast<uintptr_t>(enc_out) % 16 != 0 ||
+        (logits && reinterpret_cast<uintptr_t>(logits) % 16 != 0))
+        return set_err(ctx, ASRFE_ERR_BAD_ARG, "asrfe_decoder_forward: enc_out / embeds / logits must be 16-byte aligned");
     hipStream_t s = static_cast<hipStream_t>(stream);
     const DecoderWeights& W = *ctx->dec;
     const DecBuffers b = dec_carve(ctx, workspace, batch, tp, n_max);
     const int M = batch * tp, Md = batch * n_max;
     const int ff = W.cfg.linear_units;
     const float eps = W.cfg.ln_eps;
-    const uint16_t* mem16 = b.a_hi + 512;  // [M][512] with row stride 1536: the 16-bit head of x(t), zero past lens[b]
+    // the cross-attention memory: the 16-bit head of the encoder frames, zero past lens[b], [M][512] with row stride 1536
+    // (the middle column block of the predictor's operand).  Rebuilt from enc_out here: the workspace may be another one
+    // than the predictor's, or have been used in between.
+    if ((rc = launch_pred_split(ctx, enc_out, lens, batch, tp, b.a_hi, b.a_lo, s))) return rc;
+    const uint16_t* mem16 = b.a_hi + 512;
     if (hipMemcpyAsync(b.x, embeds, static_cast<size_t>(Md) * 512 * 4, hipMemcpyDeviceToDevice, s) != hipSuccess)
         return set_err(ctx, ASRFE_ERR_HIP, "asrfe_decoder_forward: copy of the embeddings failed");
 

@@ -57,6 +57,9 @@ int32_t launch_pred_split(asrfe_ctx* ctx, const float* enc, const int32_t* lens,
 int32_t launch_pred_alpha(asrfe_ctx* ctx, const float* conv, const float* w, float bias, float smooth, float noise,
                           const int32_t* lens, int B, int Tp, float* alphas, hipStream_t s);
 int32_t launch_cif(asrfe_ctx* ctx, const CifParams& p, int B, hipStream_t s);
+// fires [B][n_max]: the frame of each token's fire (-1 behind the fires), from alphas [B][Tp + 1] with the tail in place
+int32_t launch_cif_fire_frames(asrfe_ctx* ctx, const float* alphas, int B, int Tp, int n_max, float thr, int32_t* fires,
+                               hipStream_t s);
 int32_t launch_ln_hidden(asrfe_ctx* ctx, const uint16_t* in, uint16_t* out, int M, int width, float eps, hipStream_t s);
 int32_t launch_dec_fsmn(asrfe_ctx* ctx, const DecFsmnParams& p, int B, hipStream_t s);
 // the same from (value, column) pairs, ld per row, that the vocabulary projection's arg-max epilogue leaves

@@ -153,6 +153,32 @@ __global__ __launch_bounds__(256) void cif_kernel(const CifParams p) {
     }
 }
 
+// ---- the frame at which each token fires: cif_kernel's scalar recurrence on its own, one utterance per wave (lane 0
+//      walks the utterance's alphas, tail weight included, as cif_kernel wrote them to alphas_out) ------------------------
+__global__ __launch_bounds__(256) void cif_fire_frames_kernel(const float* __restrict__ alphas, int B, int Tp, int n_max,
+                                                              float thr, int32_t* __restrict__ fires) {
+    const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (b >= B) return;
+    int32_t* out = fires + static_cast<int64_t>(b) * n_max;
+    for (int r = lane; r < n_max; r += 64) out[r] = -1;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if (lane != 0) return;
+    const float* a = alphas + static_cast<int64_t>(b) * (Tp + 1);
+    float integrate = 0.0f;
+    int n = 0;
+    for (int t = 0; t <= Tp; ++t) {
+        integrate = integrate + a[t];
+        if (integrate >= thr) {
+            integrate = integrate - 1.0f;
+            if (n < n_max) out[n] = t;
+            ++n;
+        }
+    }
+}
+
 // ---- decoder: LayerNorm over the feed-forward hidden layer (16-bit in, normalised 16-bit out) ------------------
 // The scale and shift of this LayerNorm are folded into the second linear layer when the weights are loaded.  One
 // wave per row; NV 16-byte pieces per lane (width = 512 NV).
@@ -298,7 +324,7 @@ __global__ __launch_bounds__(256) void dec_fsmn_kernel(const DecFsmnParams p) {
 }
 
 // ---- arg-max over the vocabulary: one wave per row, the lowest index wins a tie; rows at or past the utterance's
-//      token count get -1 ------------------------------------------------------------------------------------------
+//      token count get -1, rows without a maximum (all NaN or -inf) 0 ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void argmax_kernel(const float* __restrict__ logits, int ld, int vocab, int M, int N,
                                                      const int32_t* __restrict__ token_num, int32_t* __restrict__ ids) {
     const int lane = threadIdx.x & 63;
@@ -338,7 +364,9 @@ __global__ __launch_bounds__(256) void argmax_kernel(const float* __restrict__ l
         const int oi = __shfl_xor(bi, o);
         if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
     }
-    if (lane == 0) ids[row] = bi;
+    // (a row with nothing above -inf, all NaN or all -inf, has no maximum: it reports index 0, never a value that
+    // is not a vocabulary index)
+    if (lane == 0) ids[row] = bi == 0x7fffffff ? 0 : bi;
 }
 
 // ---- arg-max from the vocabulary projection's own (value, column) pairs (one per 64-column strip): one wave per row,
@@ -367,7 +395,7 @@ __global__ __launch_bounds__(256) void argmax_pairs_kernel(const uint2* __restri
         const int oi = __shfl_xor(bi, o);
         if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
     }
-    if (lane == 0) ids[row] = bi;
+    if (lane == 0) ids[row] = bi == 0x7fffffff ? 0 : bi;  // (see argmax_kernel)
 }
 
 // ---- launchers ----------------------------------------------------------------------------------------------------
@@ -403,6 +431,14 @@ int32_t launch_cif(asrfe_ctx* ctx, const CifParams& p, int B, hipStream_t s) {
     if ((p.Tp + 1) * 4 > 64 * 1024) return set_err(ctx, ASRFE_ERR_SHAPE, "cif: more than 16383 frames per utterance");
     hipLaunchKernelGGL(cif_kernel, dim3(B), dim3(256), (p.Tp + 1) * sizeof(float), s, p);
     DEC_CHECK_LAUNCH("cif");
+    return ASRFE_OK;
+}
+
+int32_t launch_cif_fire_frames(asrfe_ctx* ctx, const float* alphas, int B, int Tp, int n_max, float thr, int32_t* fires,
+                               hipStream_t s) {
+    if (B <= 0) return ASRFE_OK;
+    hipLaunchKernelGGL(cif_fire_frames_kernel, dim3((B + 3) / 4), dim3(256), 0, s, alphas, B, Tp, n_max, thr, fires);
+    DEC_CHECK_LAUNCH("cif_fire_frames");
     return ASRFE_OK;
 }
 

@@ -18,6 +18,7 @@ import torch
 from . import _lib
 
 SOS, EOS, BLANK = 1, 2, 0
+FRAME_MS = 60  # one encoder frame: lfr_n (6) frames of 10 ms
 
 
 class ParaformerHead:
@@ -78,11 +79,12 @@ class ParaformerHead:
         return ptr, self._ws.numel() - (ptr - self._ws.data_ptr())
 
     def forward(self, encoder_out: torch.Tensor, encoder_out_lens, n_max: int | None = None, return_logits: bool = False,
-                return_alphas: bool = False):
+                return_alphas: bool = False, return_fire_frames: bool = False):
         """encoder_out [B, T', 512] float32 on the device, lens [B] -> dict with ``token_ids`` [B, n_max] int32 (-1 behind
         an utterance's tokens), ``token_num`` [B] int32, ``embeds`` [B, n_max, 512], and on request ``logits``
-        [B, n_max, vocab] and ``alphas`` [B, T' + 1].  ``n_max`` defaults to T' + 1, which always suffices (every
-        frame fires at most once)."""
+        [B, n_max, vocab], ``alphas`` [B, T' + 1] and ``fire_frames`` [B, n_max] int32 (the encoder frame at which token n
+        fires, -1 behind the fires: token n spans (fire[n - 1], fire[n]] frames of 60 ms).  ``n_max`` defaults to T' + 1,
+        which always suffices (every frame fires at most once)."""
         if not encoder_out.is_cuda or encoder_out.dtype != torch.float32 or encoder_out.dim() != 3 or encoder_out.shape[2] != 512:
             raise ValueError("ParaformerHead: encoder_out must be a float32 CUDA tensor [B, T', 512]")
         x = encoder_out.contiguous()
@@ -95,7 +97,8 @@ class ParaformerHead:
         embeds = torch.empty((b, n_max, 512), dtype=torch.float32, device=dev)
         token_num = torch.zeros((b,), dtype=torch.int32, device=dev)
         ids = torch.full((b, n_max), -1, dtype=torch.int32, device=dev)
-        alphas = torch.empty((b, tp + 1), dtype=torch.float32, device=dev) if return_alphas else None
+        alphas = torch.empty((b, tp + 1), dtype=torch.float32, device=dev) if (return_alphas or return_fire_frames) else None
+        fires = torch.full((b, n_max), -1, dtype=torch.int32, device=dev) if return_fire_frames else None
         logits = torch.empty((b * n_max, self.logits_stride), dtype=torch.float32, device=dev) if return_logits else None
         out = {"token_ids": ids, "token_num": token_num, "embeds": embeds}
         if b and tp:
@@ -105,22 +108,43 @@ class ParaformerHead:
                 self.ctx.check(self.ctx.lib.asrfe_cif_predictor(
                     self.ctx.handle, x.data_ptr(), lens.data_ptr(), b, tp, n_max, embeds.data_ptr(), token_num.data_ptr(),
                     alphas.data_ptr() if alphas is not None else None, ptr, avail, st))
+                if fires is not None:
+                    self.ctx.check(self.ctx.lib.asrfe_cif_fire_frames(self.ctx.handle, alphas.data_ptr(), b, tp, n_max,
+                                                                      fires.data_ptr(), st))
                 self.ctx.check(self.ctx.lib.asrfe_decoder_forward(
                     self.ctx.handle, x.data_ptr(), lens.data_ptr(), b, tp, embeds.data_ptr(), token_num.data_ptr(), n_max,
                     ids.data_ptr(), logits.data_ptr() if logits is not None else None, ptr, avail, st))
         if logits is not None:
             out["logits"] = logits.view(b, n_max, self.logits_stride)[:, :, : self.vocab_size]
-        if alphas is not None:
+        if alphas is not None and return_alphas:
             out["alphas"] = alphas
+        if fires is not None:
+            out["fire_frames"] = fires
         return out
 
     __call__ = forward
 
     # ---- tokens -> text ----------------------------------------------------------------------
     @staticmethod
-    def clean_ids(row) -> list:
-        """One utterance's ids with the padding (-1), sos, eos and blank entries dropped, as Paraformer.inference does."""
-        return [int(t) for t in row if int(t) >= 0 and int(t) not in (SOS, EOS, BLANK)]
+    def clean_ids(row, vocab_size: int | None = None) -> list:
+        """One utterance's ids with the padding (-1), sos, eos and blank entries dropped, as Paraformer.inference does
+        (and, given the vocabulary size, anything that is not a vocabulary index)."""
+        return [int(t) for t in row if int(t) >= 0 and int(t) not in (SOS, EOS, BLANK) and (vocab_size is None or int(t) < vocab_size)]
+
+    @staticmethod
+    def token_spans(row, fire_row, vocab_size: int | None = None) -> list:
+        """[start_ms, end_ms] of the tokens clean_ids keeps, from the frames at which the predictor fired: token n spans
+        (fire[n - 1], fire[n]] encoder frames of 60 ms (FunASR reports such per-token pairs as ``timestamp``)."""
+        spans, prev = [], 0
+        for t, f in zip(row, fire_row):
+            t, f = int(t), int(f)
+            if f < 0:
+                break
+            end = (f + 1) * FRAME_MS
+            if t >= 0 and t not in (SOS, EOS, BLANK) and (vocab_size is None or t < vocab_size):
+                spans.append([prev, end])
+            prev = end
+        return spans
 
     def ids2text(self, ids) -> str:
         """Token ids -> text with the model directory's token list: tokens are joined; a word piece ending in "@@"
@@ -145,5 +169,5 @@ class ParaformerHead:
         """-> one entry per utterance: text when a token list is known, else the list of token ids."""
         r = self.forward(encoder_out, encoder_out_lens, n_max)
         rows = r["token_ids"].cpu().tolist()
-        cleaned = [self.clean_ids(row) for row in rows]
+        cleaned = [self.clean_ids(row, self.vocab_size) for row in rows]
         return [self.ids2text(c) for c in cleaned] if self.token_list is not None else cleaned

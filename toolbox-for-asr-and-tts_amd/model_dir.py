@@ -100,6 +100,24 @@ def library_config(config: dict, small_batch_rows: int | None = None) -> _lib.Co
     return c
 
 
+def check_decoder_config(config: dict, state_dict: dict) -> None:
+    """Raises ValueError for a Paraformer directory whose predictor / decoder differs from the ones built here (its extra
+    tensors would otherwise be ignored without a word and the text would be wrong)."""
+    de = config.get("decoder_conf") or {}
+    blocks = int(de.get("num_blocks", 16))
+    att = int(de.get("att_layer_num", blocks))
+    if att != blocks:
+        raise ValueError(f"decoder_conf.att_layer_num = {att} with num_blocks = {blocks}: blocks without cross-attention are not built")
+    if any(k.startswith("decoder.decoders2.") for k in state_dict):
+        raise ValueError("the checkpoint holds decoder.decoders2.* (blocks without cross-attention): not built")
+    shift = int(de.get("sanm_shfit", de.get("sanm_shift", 0)))
+    if shift != 0:
+        raise ValueError(f"decoder_conf.sanm_shfit = {shift}: only the symmetric FSMN memory block is built")
+    predictor = config.get("predictor")
+    if predictor is not None and str(predictor) not in ("CifPredictorV2", "CifPredictorV3"):
+        raise ValueError(f"predictor = {predictor!r}: only CifPredictorV2 / CifPredictorV3 are built")
+
+
 def _read_wav(path: str) -> np.ndarray:
     with wave.open(path, "rb") as wf:
         if wf.getsampwidth() != 2:
@@ -115,9 +133,18 @@ def _read_wav(path: str) -> np.ndarray:
 class AutoModel:
     """``AutoModel(model=<local directory>, device="cuda:0")`` for a Paraformer directory; ``generate(input=...)`` takes
     what the reference passes (a WAV path, a float32 numpy array in [-1, 1] at 16 kHz, an int16 array, a torch tensor, or
-    a list of those) and returns one ``{"key", "text", "sentence_info"}`` per utterance (``"token_ids"`` too; text needs
-    the directory's token list; ``sentence_info`` is the whole utterance as one sentence of speaker 0).  ``batch`` utterances of up to ``max_seconds`` go through the device at once; longer inputs are refused
-    (the reference's VAD cuts them into segments first: that model is not part of this package)."""
+    a list of those) and returns one ``{"key", "text", "timestamp", "sentence_info"}`` per utterance (``"token_ids"``
+    too; text needs the directory's token list).  ``timestamp`` holds [start_ms, end_ms] per token from the frames at
+    which the CIF predictor fired (60 ms frames); ``sentence_info`` is the whole utterance as one sentence of speaker 0
+    from the first token's start to the last token's end (sentence splitting and speaker labels come from the
+    punctuation and speaker models, which are not part of this package; a BiCif checkpoint's own time-stamp head,
+    ``CifPredictorV3``'s upsampling branch, is not used either).  Float input goes to the device as float (the frontend
+    scales it by 32768, as FunASR's does); int16 input as int16.  ``batch`` utterances of up to ``max_seconds`` go through
+    the device at once; longer inputs are refused (the reference's VAD cuts them into segments first).
+
+    A directory whose decoder this package does not build is refused at load: ``att_layer_num`` other than
+    ``num_blocks`` (blocks without cross-attention, ``decoder.decoders2.*``), a decoder ``sanm_shfit`` other than 0
+    (asymmetric FSMN padding), or a predictor other than ``CifPredictorV2`` / ``CifPredictorV3``."""
 
     def __init__(self, model: str, device: str = "cuda:0", batch: int = 16, max_seconds: float = 30.0,
                  disable_update: bool = True, disable_pbar: bool = True, small_batch_rows: int | None = None, **kwargs):
@@ -145,6 +172,7 @@ class AutoModel:
         self._one = {}
         de = parts["config"].get("decoder_conf") or {}
         pr = parts["config"].get("predictor_conf") or {}
+        check_decoder_config(parts["config"], sd)
         vocab = len(parts["tokens"]) if parts["tokens"] else int(sd["decoder.output_layer.weight"].shape[0])
         self.head = ParaformerHead(self.engine.ctx, num_blocks=int(de.get("num_blocks", 16)),
                                    linear_units=int(de.get("linear_units", 2048)), vocab_size=vocab,
@@ -171,7 +199,10 @@ class AutoModel:
 
     # ---- input handling ----------------------------------------------------------------------------------------------
     @staticmethod
-    def _to_int16(x) -> np.ndarray:
+    def _to_pcm(x) -> np.ndarray:
+        """-> int16 samples (a WAV path, an int16 array) or float32 samples in [-1, 1) (anything else).  Float samples stay
+        float: FunASR's frontend multiplies them by 32768 without rounding to the int16 grid, and so does the device
+        frontend; a resampled chunk is then not quantised a second time."""
         if isinstance(x, str):
             return _read_wav(x)
         if isinstance(x, torch.Tensor):
@@ -181,8 +212,15 @@ class AutoModel:
             a = a.reshape(-1)
         if a.dtype == np.int16:
             return a
-        # float PCM in [-1, 1): FunASR's loader scales by 32768 in the frontend; rounding to the int16 grid first is what
-        # a WAV file of the same signal would hold
+        return np.ascontiguousarray(a, dtype=np.float32)
+
+    @staticmethod
+    def _to_int16(x) -> np.ndarray:
+        """int16 samples of any input (the streaming voice-activity frontend keeps its sample tail as int16): float PCM
+        is rounded to the int16 grid, which is what a WAV file of the same signal would hold."""
+        a = AutoModel._to_pcm(x)
+        if a.dtype == np.int16:
+            return a
         return np.clip(np.rint(a.astype(np.float64) * 32768.0), -32768, 32767).astype(np.int16)
 
     def generate(self, input, cache=None, is_final: bool | None = None, **kwargs) -> list:
@@ -190,7 +228,7 @@ class AutoModel:
             return self._vad.generate(input, cache=cache, is_final=is_final, **kwargs)
         items = list(input) if isinstance(input, (list, tuple)) else [input]
         keys = [os.path.splitext(os.path.basename(x))[0] if isinstance(x, str) else f"rand_key_{i}" for i, x in enumerate(items)]
-        clips = [self._to_int16(x) for x in items]
+        clips = [self._to_pcm(x) for x in items]
         for k, c in zip(keys, clips):
             if c.shape[0] > self.max_samples:
                 raise ValueError(f"{k}: {c.shape[0]} samples exceed the engine's {self.max_samples}; cut the input into segments")
@@ -200,22 +238,31 @@ class AutoModel:
             idx = order[lo:lo + self.batch]
             n = max(clips[i].shape[0] for i in idx)
             eng = self._engine_for(len(idx), n)
-            pcm = np.zeros((eng.batch, max(n, 1)), dtype=np.int16)
+            # a batch with any float clip travels as float32 (int16 / 32768 is exact in float32 and comes back as the
+            # same integer after the frontend's scaling, so the int16 clips beside it are not changed by that)
+            as_float = any(clips[i].dtype != np.int16 for i in idx)
+            pcm = np.zeros((eng.batch, max(n, 1)), dtype=np.float32 if as_float else np.int16)
             lens = np.zeros((eng.batch,), dtype=np.int32)
             for row, i in enumerate(idx):
-                pcm[row, :clips[i].shape[0]] = clips[i]
-                lens[row] = clips[i].shape[0]
+                c = clips[i]
+                pcm[row, :c.shape[0]] = c.astype(np.float32) / np.float32(32768.0) if (as_float and c.dtype == np.int16) else c
+                lens[row] = c.shape[0]
             out, olens = eng.run(torch.from_numpy(pcm).to(self.device), torch.from_numpy(lens).to(self.device))
-            r = self.head.forward(out, olens)
+            r = self.head.forward(out, olens, return_fire_frames=True)
             rows = r["token_ids"].cpu().tolist()
+            fires = r["fire_frames"].cpu().tolist()
             for row, i in enumerate(idx):
-                ids = self.head.clean_ids(rows[row])
+                ids = self.head.clean_ids(rows[row], self.head.vocab_size)
                 item = {"key": keys[i], "token_ids": ids}
                 item["text"] = self.head.ids2text(ids) if self.head.token_list is not None else ""
                 # the reference reads rec_result[0]["sentence_info"] = [{"text", "start" (ms), "end" (ms), "spk"}]
-                # (voice_interface.py:2064-2067, 2092-2093, 2124-2126).  Sentence splitting and speaker labels come from
-                # models that are not part of this package: the utterance is reported as one sentence of speaker 0
+                # (voice_interface.py:2064-2067, 2092-2093, 2124-2126).  Times come from the frames at which the
+                # predictor fired (a token ends with the frame that completes it); sentence splitting and speaker
+                # labels come from models that are not part of this package: one sentence of speaker 0
                 dur_ms = int(round(1000.0 * clips[i].shape[0] / self.engine.ctx.cfg.sample_rate))
-                item["sentence_info"] = [{"text": item["text"], "start": 0, "end": dur_ms, "spk": 0}] if ids else []
+                spans = [[min(a, dur_ms), min(b, dur_ms)] for a, b in self.head.token_spans(rows[row], fires[row], self.head.vocab_size)]
+                item["timestamp"] = spans
+                item["sentence_info"] = [{"text": item["text"], "start": spans[0][0], "end": spans[-1][1], "spk": 0,
+                                          "timestamp": spans}] if ids else []
                 results[i] = item
         return results
