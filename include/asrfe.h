@@ -125,8 +125,12 @@ int32_t asrfe_load_cmvn(asrfe_ctx* ctx, const float* shift_host, const float* sc
  * With ASRFE_DT_F16 operands the call first proves that no activation the kernels round to fp16 can leave the fp16
  * range: q, k, v, the attention output, the FSMN memory and the feed-forward hidden layer are linear images of a
  * normalised row n (||n||_2 = sqrt(K)), so |w . n + c| <= ||w||_2 sqrt(K) + |c| bounds them from the weights alone.
- * Weights that fail the bound are refused with ASRFE_ERR_RANGE (load them into a context created with
- * ASRFE_DT_BF16); ordinary checkpoints stay orders of magnitude below it.  Independently of the proof the kernels
+ * Where a bound fails and the function allows it, the call first moves a power of two between partners, which changes
+ * no result and rounds nothing: between dimension j of q and of k (a score is sum_j q_j k_j), and between a hidden
+ * unit's row of W1 / b1 and its column of W2 (ReLU is positively homogeneous).  Weights that pass keep their bits.
+ * What still fails - v, the attention output and the FSMN memory have no such partner - is refused with
+ * ASRFE_ERR_RANGE (load it into a context created with ASRFE_DT_BF16); ordinary checkpoints stay orders of magnitude
+ * below the bound.  Independently of the proof the kernels
  * convert to fp16 with saturation (+-65504, never an infinity). */
 int32_t asrfe_load_encoder_weights(asrfe_ctx* ctx, const asrfe_tensor_desc* descs, int32_t n);
 

@@ -173,19 +173,71 @@ def test_fp16_operands_hold_large_hidden_activations(pkg):
     assert err <= ENC_TOL, err
 
 
-def test_weights_beyond_the_fp16_range_are_refused_and_load_as_bf16(pkg):
-    """w_1 x 65536 puts the proven bound of the hidden layer (||w||_2 sqrt(512) + |b|) beyond 65504: the fp16 context
-    refuses the load with ASRFE_ERR_RANGE and a message naming the layer; a bf16 context takes the same weights and
-    produces finite output."""
+def test_hidden_units_beyond_the_fp16_range_are_rescaled_exactly(pkg):
+    """w_1 x 65536 puts the proven bound of the hidden layer (||w||_2 sqrt(512) + |b|) beyond 65504.  The fp16 context
+    moves a power of two from each such unit's row of w_1 into its column of w_2 while loading (the function is
+    unchanged, nothing is rounded), so the load is accepted and the output stays within 1e-2 of the fp64 oracle."""
     cfg = so.SanmConfig(num_blocks=2)
     sd = _scaled_ffn(so.make_state_dict(cfg, seed=33, dtype=torch.float32), 65536.0)
+    bound = float(sd["encoders.0.feed_forward.w_1.weight"].double().norm(dim=1).max()) * math.sqrt(512.0)
+    assert bound > 65504.0
+    feats = so.synth_feats(2, 130, 560, seed=34)
+    lens = torch.tensor([130, 71], dtype=torch.int32)
     enc = pkg.SANMEncoder(num_blocks=2)
-    with pytest.raises(pkg.AsrfeError, match="feed-forward hidden layer.*fp16 range") as ei:
-        enc.load_state_dict(sd)
+    enc.load_state_dict(sd)
+    out, _, _ = enc.forward(feats.cuda(), lens)
+    want, _ = so.encoder_forward(feats.double(), lens, {k: v.double() for k, v in sd.items()}, cfg)
+    assert bool(torch.isfinite(out).all())
+    err = float((out.cpu().double() - want).abs().max())
+    assert err <= ENC_TOL, err
+    # the throughput plan reads the same rescaled weights from its per-layer stream
+    big = so.synth_feats(9, 256, 560, seed=35)
+    blens = torch.tensor([256] * 8 + [100], dtype=torch.int32)
+    outb, _, _ = enc.forward(big.cuda(), blens)
+    wantb, _ = so.encoder_forward(big.double(), blens, {k: v.double() for k, v in sd.items()}, cfg)
+    errb = float((outb.cpu().double() - wantb).abs().max())
+    assert errb <= ENC_TOL, errb
+
+
+def test_q_beyond_the_fp16_range_is_balanced_against_k(pkg):
+    """q rows x 2^18 and k rows x 2^-18: every score q . k is what it was, but q's bound leaves the fp16 range (and k
+    sinks towards its subnormals).  The load call moves the power of two back, dimension by dimension; the output stays
+    within 1e-2 of the fp64 oracle in both layers' positions (layer 0 has its own 560-wide projection)."""
+    cfg = so.SanmConfig(num_blocks=3)
+    sd = so.make_state_dict(cfg, seed=36, dtype=torch.float32)
+    for layer in ("encoders0.0", "encoders.1"):
+        for part in ("weight", "bias"):
+            k = f"{layer}.self_attn.linear_q_k_v.{part}"
+            v = sd[k].clone()
+            v[:512] *= 2.0 ** 18
+            v[512:1024] *= 2.0 ** -18
+            sd[k] = v
+    feats = so.synth_feats(2, 130, 560, seed=37)
+    lens = torch.tensor([130, 71], dtype=torch.int32)
+    enc = pkg.SANMEncoder(num_blocks=3)
+    enc.load_state_dict(sd)
+    out, _, _ = enc.forward(feats.cuda(), lens)
+    want, _ = so.encoder_forward(feats.double(), lens, {k: v.double() for k, v in sd.items()}, cfg)
+    err = float((out.cpu().double() - want).abs().max())
+    assert err <= ENC_TOL, err
+
+
+def test_what_cannot_be_rescaled_is_refused_and_loads_as_bf16(pkg):
+    """v feeds the FSMN memory, which joins the residual stream as it is: no partner to take its scale.  v rows x 1e5
+    are refused with ASRFE_ERR_RANGE and a message naming the layer; so are q and k when both are beyond the range
+    (balancing leaves each at the geometric mean).  A bf16 context takes the same weights."""
+    cfg = so.SanmConfig(num_blocks=2)
+    sd = so.make_state_dict(cfg, seed=33, dtype=torch.float32)
+    w = sd["encoders.0.self_attn.linear_q_k_v.weight"].clone()
+    w[1024:] *= 1e5
+    sd["encoders.0.self_attn.linear_q_k_v.weight"] = w
+    with pytest.raises(pkg.AsrfeError, match=r"layer 1 v \(and the attention output\).*fp16 range") as ei:
+        pkg.SANMEncoder(num_blocks=2).load_state_dict(sd)
     assert ei.value.code == -7
-    # q / k / v are checked the same way
     sd2 = so.make_state_dict(cfg, seed=33, dtype=torch.float32)
-    sd2["encoders.0.self_attn.linear_q_k_v.weight"] = sd2["encoders.0.self_attn.linear_q_k_v.weight"] * 1e5
+    w = sd2["encoders.0.self_attn.linear_q_k_v.weight"].clone()
+    w[:1024] *= 1e5
+    sd2["encoders.0.self_attn.linear_q_k_v.weight"] = w
     with pytest.raises(pkg.AsrfeError, match="layer 1 q / k"):
         pkg.SANMEncoder(num_blocks=2).load_state_dict(sd2)
     encb = pkg.SANMEncoder(num_blocks=2, compute_dtype="bfloat16")

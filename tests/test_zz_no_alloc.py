@@ -53,6 +53,25 @@ def test_static_scratch_forward_equals_workspace_forward(enc):
     assert float((got2.cpu() - ref).abs().max()) <= 1e-2
 
 
+def test_static_scratch_on_the_throughput_plan(enc):
+    """Above 2048 rows a call takes the throughput plan, whose residual stream lives in the array in whole 128-row tiles
+    (register order): 9 x 256 = 2304 rows right behind a call with a larger footprint, then 2057 rows (9 x 230 with ragged
+    lengths: not a multiple of 128, so the last tile's padding rows hold what the call before left there)."""
+    big, _ = _both(enc, so.synth_feats(10, 300, 560, seed=44), [300] * 10)        # 3000 rows: the larger footprint
+    assert bool(torch.isfinite(big).all())
+    got, want = _both(enc, so.synth_feats(9, 256, 560, seed=45), [256] * 9)
+    assert bool(torch.isfinite(want).all()) and torch.equal(got, want)
+    lens = [230, 229, 128, 1, 230, 64, 0, 200, 230]
+    feats = so.synth_feats(9, 230, 560, seed=46)
+    assert 9 * 230 > 2048 and (9 * 230) % 128 != 0
+    got2, want2 = _both(enc, feats, lens)
+    assert bool(torch.isfinite(want2).all()) and torch.equal(got2, want2)
+    ref, _ = so.encoder_forward(feats, torch.tensor(lens, dtype=torch.int32),
+                                so.make_state_dict(so.SanmConfig(num_blocks=3), seed=41, dtype=torch.float32),
+                                so.SanmConfig(num_blocks=3))
+    assert float((got2.cpu() - ref).abs().max()) <= 1e-2
+
+
 def test_static_scratch_refuses_what_does_not_fit(enc):
     import toolbox_for_asr_and_tts_amd as pkg
     ctx = enc.ctx

@@ -450,6 +450,71 @@ static int32_t up_layer_stream(asrfe_ctx* ctx, const HostTensor* wo, const HostT
 // q, k, v, the attention output (a convex combination of v rows), the FSMN memory (v plus 11 taps of v) and the
 // feed-forward hidden layer, and refuses weights whose bound passes the largest fp16 number: such a model needs
 // ASRFE_DT_BF16.  (The kernels additionally convert with saturation, so even then no infinity would arise.)
+//
+// Two of these bounds can be lowered without changing the function the layer computes, and the load call does so
+// before it judges (only for rows whose bound passes the fp16 range, so weights that pass as they are keep their bits):
+//   * a score is sum_j q_j k_j: multiplying dimension j of q by 2^-e and the same dimension of k by 2^e leaves every
+//     score as it was.  rebalance_qk moves the excess of one side to the other, dimension by dimension;
+//   * ReLU is positively homogeneous: W2 relu(W1 n + b1) = (W2 diag(s)) relu(diag(1 / s) (W1 n + b1)) for s > 0.
+//     rescale_hidden divides a hidden unit's row of W1 and its bias by 2^e and multiplies its column of W2 by 2^e.
+// Powers of two, so nothing is rounded.  v, the attention output and the FSMN memory have no such partner (the FSMN
+// memory reaches the residual stream directly): their refusal stands.
+static void rebalance_qk(std::vector<float>& w, std::vector<float>& c, int64_t d, int64_t din, int heads) {
+    (void)heads;  // (a dimension of one head pairs q row r with k row d + r whatever the head count)
+    std::vector<double> bq(static_cast<size_t>(d)), bk(static_cast<size_t>(d));
+    linear_bound(w, c, 3 * d, din, 0, d, &bq);
+    linear_bound(w, c, 3 * d, din, d, 2 * d, &bk);
+    for (int64_t r = 0; r < d; ++r) {
+        if (bq[r] <= kF16Max && bk[r] <= kF16Max) continue;
+        if (!(bq[r] > 0.0) || !(bk[r] > 0.0) || !std::isfinite(bq[r]) || !std::isfinite(bk[r])) continue;
+        // equal bounds on both sides: q row / 2^e, k row * 2^e with 2^e = sqrt(bq / bk) rounded to a power of two
+        const int e = static_cast<int>(std::lround(0.5 * std::log2(bq[r] / bk[r])));
+        const float down = std::ldexp(1.0f, -e), up = std::ldexp(1.0f, e);
+        for (int64_t i = 0; i < din; ++i) {
+            w[r * din + i] *= down;
+            w[(d + r) * din + i] *= up;
+        }
+        c[r] *= down;
+        c[d + r] *= up;
+    }
+}
+
+// -> false when a column of W2 would leave the fp16 range itself after the rescale (worst: the offending bound)
+static bool rescale_hidden(std::vector<float>& w1, std::vector<float>& b1, const HostTensor* w2, std::vector<float>& w2s,
+                           int64_t ff, int64_t d, double* worst) {
+    std::vector<double> bound(static_cast<size_t>(ff));
+    linear_bound(w1, b1, ff, d, 0, ff, &bound);
+    bool any = false;
+    for (int64_t r = 0; r < ff; ++r) {
+        if (bound[r] <= kF16Max || !std::isfinite(bound[r])) continue;
+        if (!any) w2s.assign(w2->data, w2->data + w2->numel());
+        any = true;
+        int e = static_cast<int>(std::ceil(std::log2(bound[r] / 16384.0)));
+        // A unit this large usually comes with a tiny column of W2 (their product is what the model learnt): lift the
+        // column towards 2^-8, out of fp16's subnormals, while the unit's bound stays above 256.
+        double colmax = 0.0;
+        for (int64_t o = 0; o < d; ++o) colmax = std::fmax(colmax, std::fabs(static_cast<double>(w2s[o * ff + r])));
+        colmax = std::ldexp(colmax, e);
+        if (colmax > 0.0 && colmax < 0x1p-8) {
+            const int lift = static_cast<int>(std::floor(std::log2(0x1p-8 / colmax)));
+            const int room = static_cast<int>(std::floor(std::log2(std::ldexp(bound[r], -e) / 256.0)));
+            e += std::max(0, std::min(lift, room));
+        }
+        const float down = std::ldexp(1.0f, -e), up = std::ldexp(1.0f, e);
+        for (int64_t i = 0; i < d; ++i) w1[r * d + i] *= down;
+        b1[r] *= down;
+        for (int64_t o = 0; o < d; ++o) {
+            float& v = w2s[o * ff + r];
+            v *= up;
+            if (std::fabs(static_cast<double>(v)) > kF16Max) {
+                *worst = std::fabs(static_cast<double>(v));
+                return false;
+            }
+        }
+    }
+    return true;
+}
+
 static int32_t range_refusal(asrfe_ctx* ctx, int layer, const char* what, double bound) {
     char buf[256];
     std::snprintf(buf, sizeof(buf),
@@ -480,6 +545,7 @@ extern "C" int32_t asrfe_load_encoder_weights(asrfe_ctx* ctx, const asrfe_tensor
             return r;
         fold_layernorm(tw, tc, tg, tb, wfold, cfold);
         *w_shape = tw;
+        if (c.enc_compute_dtype == ASRFE_DT_F16) rebalance_qk(wfold, cfold, d, din, c.enc_heads);
         return ASRFE_OK;
     };
     const bool check_range = c.enc_compute_dtype == ASRFE_DT_F16;
@@ -533,13 +599,20 @@ extern "C" int32_t asrfe_load_encoder_weights(asrfe_ctx* ctx, const asrfe_tensor
             return rc;
         fold_layernorm(tw, tc, tg, tb, wfold, cfold);
         const HostTensor w1view{wfold.data(), tw->shape};
+        if ((rc = need(ctx, m, p + ".feed_forward.w_2.weight", {d, ff}, &t))) return rc;
+        std::vector<float> w2s;  // W2 with rescaled columns, when a hidden unit had to be brought into the fp16 range
+        HostTensor w2view{t->data, t->shape};
         if (check_range) {
+            double worst = 0.0;
+            if (!rescale_hidden(wfold, cfold, t, w2s, ff, d, &worst))
+                return range_refusal(ctx, li, "feed-forward output weight (after moving the hidden layer's scale into it)", worst);
+            if (!w2s.empty()) w2view.data = w2s.data();
             const double bh = linear_bound(wfold, cfold, ff, d, 0, ff);
             if (bh > kF16Max) return range_refusal(ctx, li, "feed-forward hidden layer", bh);
         }
+        t = &w2view;
         if (row_major && (rc = up_bf16(ctx, &w1view, static_cast<int>(d), &L.w_ffn1))) return rc;
         if ((rc = upload(ctx, cfold, &L.b_ffn1))) return rc;
-        if ((rc = need(ctx, m, p + ".feed_forward.w_2.weight", {d, ff}, &t))) return rc;
         if (row_major && (rc = up_bf16(ctx, t, static_cast<int>(ff), &L.w_ffn2))) return rc;
         if (d != 512 || ff % 64 != 0 || ff > 7168)
             return set_err(ctx, ASRFE_ERR_SHAPE, "asrfe_load_encoder_weights: the fused post-attention kernel needs d = 512 and linear_units a multiple of 64 up to 7168");

@@ -214,7 +214,10 @@ def create_app(engine, decoder: Optional[Callable] = None, clock: Optional[Calla
                                                "code": "AUDIO_DECODE_ERROR"})
                     continue
                 try:
-                    state = session.process_chunk(chunk, now())
+                    # on the engine's worker thread like every other device call: a chunk is copied into the session's
+                    # device buffer and, with a VAD model, goes through its network; neither belongs on the event loop,
+                    # and the one worker keeps device work in order
+                    state = await on_engine(session.process_chunk, chunk, now())
                     if state["should_finalize"]:
                         await websocket.send_json({"type": "processing", "status": "finalizing",
                                                    "message": "processing audio"})
