@@ -26,6 +26,10 @@ Files written:
   decoder_tiny.npz             : CIF predictor + 2-block decoder (vocabulary 300), B=2, T'=48 ragged: memory, alphas,
                                  token counts, embeddings, logits, arg-max ids (fp64 oracle)
 
+``python tests/golden/make_golden.py witness`` writes nothing: it checks the oracles whose modules have a second,
+independent implementation in the build image against it (second_witnesses below; tests/test_second_witness_cpu.py runs
+the same functions).
+
 ``python tests/golden/make_golden.py full`` writes only the two full-size encoder fixtures (several minutes of CPU
 time), ``... decoder`` only the decoder fixture, ``... vocoder`` only the vocoder fixture
 (vocoder_tiny.npz: HiFi-GAN generator with 128 channels and two stages, B=2, 16 mel frames: mel, waveform).
@@ -188,8 +192,93 @@ def vocoder_goldens():
     print("vocoder tiny:", tuple(wav.shape), "abs max", float(wav.abs().max()))
 
 
+# ---- second witnesses: independent implementations of the same published modules, importable in the build image ----
+def witness_hifigan(initial_channel=128, rates=(4, 2), kernels=(8, 4), frames=16, seed=9):
+    """The HiFi-GAN oracle against ``transformers.SpeechT5HifiGan`` (its own port of the published generator: conv_pre,
+    leaky_relu -> transposed convolution -> mean of the residual blocks per stage, leaky_relu 0.01, conv_post, tanh) with
+    the oracle's seeded weights, in fp64.  -> max |oracle - transformers| over the waveform."""
+    from transformers import SpeechT5HifiGan, SpeechT5HifiGanConfig
+
+    from oracle import hifigan_oracle as ho
+
+    cfg = ho.HifiganConfig(initial_channel=initial_channel, upsample_rates=tuple(rates), upsample_kernels=tuple(kernels))
+    sd = {k: v.double() for k, v in ho.make_state_dict(cfg, seed=seed).items()}
+    model = SpeechT5HifiGan(SpeechT5HifiGanConfig(
+        model_in_dim=cfg.n_mels, upsample_initial_channel=initial_channel, upsample_rates=list(rates),
+        upsample_kernel_sizes=list(kernels), resblock_kernel_sizes=list(cfg.resblock_kernels),
+        resblock_dilation_sizes=[list(d) for d in cfg.resblock_dilations], leaky_relu_slope=cfg.lrelu_slope,
+        normalize_before=False)).double().eval()
+    theirs = {k.replace("ups.", "upsampler."): v for k, v in sd.items()}
+    own = model.state_dict()
+    missing = [k for k in own if k not in theirs and k not in ("mean", "scale")]
+    extra = [k for k in theirs if k not in own]
+    assert not missing and not extra, (missing, extra)
+    model.load_state_dict({**theirs, "mean": own["mean"], "scale": own["scale"]})
+    mel = torch.randn(2, cfg.n_mels, frames, generator=torch.Generator().manual_seed(seed + 1), dtype=torch.float32).double()
+    with torch.no_grad():
+        want = model(mel.transpose(1, 2))
+    got = ho.generator_forward(mel, sd, cfg)
+    assert want.shape == got.shape, (want.shape, got.shape)
+    return float((want - got).abs().max())
+
+
+def witness_sanm_attention(b=2, t=70, lens=(70, 41), seed=21, layer="encoders.0"):
+    """MultiHeadedAttentionSANM of the encoder oracle against two torch modules, in fp64, with the oracle's weights:
+    ``nn.MultiheadAttention`` (packed in-projection = linear_q_k_v, out_proj = linear_out, key_padding_mask) for the
+    softmax core and ``nn.Conv1d(512, 512, 11, padding=5, groups=512, bias=False)`` for the FSMN memory (plus its
+    identity path and the masks).  -> (max |difference| on valid rows, max |FSMN part alone|)."""
+    cfg = so.SanmConfig(num_blocks=2)
+    sd = so.make_state_dict(cfg, seed=seed, dtype=torch.float64)
+    d = cfg.output_size
+    x = so.synth_feats(b, t, d, seed=seed + 1, dtype=torch.float64)
+    ln = torch.tensor(lens, dtype=torch.int32)
+    mask = (torch.arange(t)[None, :] < ln[:, None]).double()
+    got = so._attention_sanm(x, mask, sd, layer, cfg)
+
+    mha = torch.nn.MultiheadAttention(d, cfg.attention_heads, bias=True, batch_first=True, dtype=torch.float64).eval()
+    conv = torch.nn.Conv1d(d, d, cfg.kernel_size, padding=(cfg.kernel_size - 1) // 2, groups=d, bias=False, dtype=torch.float64)
+    with torch.no_grad():
+        mha.in_proj_weight.copy_(sd[f"{layer}.self_attn.linear_q_k_v.weight"])
+        mha.in_proj_bias.copy_(sd[f"{layer}.self_attn.linear_q_k_v.bias"])
+        mha.out_proj.weight.copy_(sd[f"{layer}.self_attn.linear_out.weight"])
+        mha.out_proj.bias.copy_(sd[f"{layer}.self_attn.linear_out.bias"])
+        conv.weight.copy_(sd[f"{layer}.self_attn.fsmn_block.weight"])
+        core, _ = mha(x, x, x, key_padding_mask=mask == 0, need_weights=False)
+        v = torch.nn.functional.linear(x, sd[f"{layer}.self_attn.linear_q_k_v.weight"][2 * d:],
+                                       sd[f"{layer}.self_attn.linear_q_k_v.bias"][2 * d:]) * mask[:, :, None]
+        fsmn = (conv(v.transpose(1, 2)).transpose(1, 2) + v) * mask[:, :, None]
+    valid = mask[:, :, None] > 0
+    diff = torch.where(valid, got - (core + fsmn), torch.zeros_like(got))
+    # scaled_dot_product_attention as a third voice for the core alone
+    h, dk = cfg.attention_heads, d // cfg.attention_heads
+    qkv = torch.nn.functional.linear(x, sd[f"{layer}.self_attn.linear_q_k_v.weight"], sd[f"{layer}.self_attn.linear_q_k_v.bias"])
+    q, k, vv = (z.reshape(b, t, h, dk).transpose(1, 2) for z in torch.split(qkv, d, dim=-1))
+    with torch.no_grad():
+        ctx = torch.nn.functional.scaled_dot_product_attention(q, k, vv, attn_mask=(mask > 0)[:, None, None, :])
+        sdpa = torch.nn.functional.linear(ctx.transpose(1, 2).reshape(b, t, d), sd[f"{layer}.self_attn.linear_out.weight"],
+                                          sd[f"{layer}.self_attn.linear_out.bias"])
+    diff2 = torch.where(valid, got - (sdpa + fsmn), torch.zeros_like(got))
+    return max(float(diff.abs().max()), float(diff2.abs().max())), float(fsmn.abs().max())
+
+
+def second_witnesses():
+    e = witness_hifigan()
+    print(f"hifigan oracle vs transformers.SpeechT5HifiGan (128 ch, 4x2): {e:.3e}")
+    assert e < 1e-12, e
+    e = witness_hifigan(initial_channel=64, rates=(8, 8, 2, 2), kernels=(16, 16, 4, 4), frames=12, seed=19)
+    print(f"hifigan oracle vs transformers.SpeechT5HifiGan (64 ch, 8x8x2x2 = the deployed stage layout): {e:.3e}")
+    assert e < 1e-12, e
+    e, size = witness_sanm_attention()
+    print(f"SAN-M attention oracle vs nn.MultiheadAttention / SDPA + nn.Conv1d(groups=512): {e:.3e} (FSMN part up to {size:.3f})")
+    assert e < 1e-12 and size > 1e-3, (e, size)
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "witness":
+        second_witnesses()
+        return
     if len(sys.argv) > 1 and sys.argv[1] == "vocoder":
+        witness_hifigan()
         vocoder_goldens()
         return
     if len(sys.argv) > 1 and sys.argv[1] == "full":
