@@ -371,6 +371,10 @@ def main():
                 "streams_per_gpu": args.streams,
             },
             "output_finite": out_ok,
+            # what one rank has of the host: the step is launched from one thread, but a rank that shares a core with
+            # another shows up as launch gaps at N = 8
+            "host": {"cores_per_rank": len(os.sched_getaffinity(0)), "cpus_on_box": os.cpu_count(),
+                     "torch_threads_per_rank": torch.get_num_threads()},
             "achieved_tflops_all": value * ALL_FLOP_PER_UTT / 1e12 / world,
             "counter_profile": counter_profile()[1],
         }

@@ -123,3 +123,16 @@ def test_two_rank_gloo_sharding():
                        capture_output=True, text=True, timeout=300, env=env, cwd=ROOT)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "SHARD_OK" in r.stdout
+
+
+def test_eight_rank_gloo_plans():
+    """The node's full width on CPU: eight gloo ranks divide the batch the three ways bench.py and AsrEngine do
+    (weak 64 per rank, strong 512 split, ragged 512 dealt out by length); each is a partition, the ragged one is
+    balanced to within one clip of audio, and sampled clips give the single-process oracle's features."""
+    script = os.path.join(ROOT, "tests", "gloo_shard_worker.py")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29541", OMP_NUM_THREADS="1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=8",
+                        "--master-addr", "127.0.0.1", "--master-port", "29541", script, "plans"],
+                       capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "PLANS_OK 8" in r.stdout
