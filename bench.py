@@ -469,6 +469,21 @@ def main():
             head.forward(o, l, n_max=256)
 
         t_text = timed(step_text, max(2, args.steps // 2))
+        # matrix work of the step behind the encoder: per decoder block the feed-forward (512 -> 2048 -> 512), the query
+        # and output projections on the token rows, the key / value projection on the encoder frames and the cross
+        # attention; the closing feed-forward, the vocabulary projection and the predictor's three products
+        md, mf = args.batch * 256, args.batch * TP
+        dec_flop = (16 * (2 * gemm_flops(md, 2048, 512) + 2 * gemm_flops(md, 512, 512) + gemm_flops(mf, 1024, 512)
+                          + args.batch * 4 * 2 * gemm_flops(256, TP, 128))
+                    + 2 * gemm_flops(md, 2048, 512) + gemm_flops(md, 8448, 512) + 3 * gemm_flops(mf, 512, 1536))
+        result["roofline_decoder"] = {
+            "kernel": "CIF predictor + 16 decoder blocks + vocabulary projection with arg-max epilogue, 64 x 256 token rows "
+                      "over 64 x 500 encoder frames (about 165 launches; the products run on gemm_bf16_kernel)",
+            "bound": "mfma", "achieved": dec_flop / t_head / 1e12, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "frac": dec_flop / t_head / 1e12 / MFMA_BF16_PEAK_TFLOPS, "traffic": None,
+            "flop_per_step": dec_flop,
+            "note": "all products of one step over the step's wall time (memory-bound passes included in the time)",
+        }
         result["with_decoder"] = {
             "head_ms_per_step": 1e3 * t_head, "chain_ms_per_step": 1e3 * t_text, "chain_utt_per_s": args.batch / t_text,
             "tokens_per_clip_mean": sum(tok) / len(tok), "n_max": 256,

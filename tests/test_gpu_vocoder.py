@@ -134,6 +134,28 @@ def test_generator_batch_128_properties(pkg):
     assert float((wav[77].cpu().double() - want[0]).abs().max()) <= WAV_TOL
 
 
+def test_generator_at_the_vocoder_configurations_shape(pkg):
+    """128 items of 94 mel frames (one second each), the shape the vocoder rate is quoted on, as one call: items 0, 63
+    and 127 equal the same item run alone bit for bit (no item sees its neighbours through a position tile that spans
+    two of them), items 63 and 127 are within 1e-2 of the oracle, and the per-item sums add up to the batch's sum."""
+    cfg = ho.HifiganConfig()
+    gen, sd = build(cfg, seed=29)
+    mel = torch.randn(128, 80, 94, generator=torch.Generator().manual_seed(30))
+    wav = gen.forward(mel.cuda()).clone()
+    torch.cuda.synchronize()
+    assert wav.shape == (128, 94 * 256) and bool(torch.isfinite(wav).all())
+    for k in (0, 63, 127):
+        alone = gen.forward(mel[k:k + 1].cuda())
+        assert torch.equal(alone[0], wav[k]), k
+    sd64 = {k: v.double() for k, v in sd.items()}
+    want = ho.generator_forward(mel[[63, 127]].double(), sd64, cfg)
+    err = float((wav[[63, 127]].cpu().double() - want).abs().max())
+    assert err <= WAV_TOL and float(want.abs().max()) > 0.05, err
+    per_item = wav.double().sum(dim=1)
+    assert abs(float(per_item.sum()) - float(wav.double().sum())) <= 1e-9 * float(wav.double().abs().sum())
+    print(f"128 x 94 frames: max waveform error of items 63, 127: {err:.3e}")
+
+
 def test_weight_norm_pairs_and_wav_bytes(pkg):
     """A state_dict with weight norm still in place loads to the same generator; wav_bytes is a 16-bit mono WAV image."""
     from toolbox_for_asr_and_tts_amd.vocoder import HiFiGANGenerator

@@ -61,7 +61,7 @@ static int32_t dec_range_refusal(asrfe_ctx* ctx, const std::string& what, double
 // a linear layer behind a LayerNorm: fold, prove the fp16 range of its output when asked, upload as 16-bit + f32 bias
 static int32_t up_folded(asrfe_ctx* ctx, const TensorMap& m, const std::string& wname, const std::string& bname,
                          const std::string& gname, const std::string& betaname, int64_t n, int64_t k, int64_t n_pad,
-                         bool prove, const std::string& what, uint16_t** w_dev, float** b_dev) {
+                         bool prove, const std::string& what, uint16_t** w_dev, float** b_dev, float** rowsum_dev = nullptr) {
     const HostTensor *tw, *tc = nullptr, *tg, *tb;
     int32_t rc;
     if ((rc = need(ctx, m, wname, {n, k}, &tw, kWho)) || (rc = need(ctx, m, gname, {k}, &tg, kWho)) ||
@@ -76,6 +76,20 @@ static int32_t up_folded(asrfe_ctx* ctx, const TensorMap& m, const std::string& 
     }
     cf.resize(static_cast<size_t>(n_pad), 0.0f);
     if ((rc = up_16(ctx, wf.data(), n, k, n_pad, k, w_dev)) || (rc = upload(ctx, cf, b_dev))) return rc;
+    if (rowsum_dev) {
+        // sums of the weights as the device holds them (rounded to the 16-bit operand type)
+        const bool f16 = ctx->cfg.enc_compute_dtype == ASRFE_DT_F16;
+        std::vector<float> rs(static_cast<size_t>(n_pad), 0.0f);
+        for (int64_t r = 0; r < n; ++r) {
+            double acc = 0.0;
+            for (int64_t i = 0; i < k; ++i) {
+                const float w = wf[r * k + i];
+                acc += f16 ? f16_to_f32(f16_rne(w)) : bf16_to_f32(bf16_rne(w));
+            }
+            rs[r] = static_cast<float>(acc);
+        }
+        if ((rc = upload(ctx, rs, rowsum_dev))) return rc;
+    }
     return ASRFE_OK;
 }
 
@@ -131,19 +145,19 @@ extern "C" int32_t asrfe_load_decoder_weights(asrfe_ctx* ctx, const asrfe_decode
     }
 
     // ---- decoder blocks
-    auto ffn = [&](const std::string& p, uint16_t** w1, float** b1, uint16_t** w2, float** b2) -> int32_t {
+    auto ffn = [&](const std::string& p, uint16_t** w1, float** b1, uint16_t** w2, float** b2, float** c2) -> int32_t {
         int32_t r;
         if ((r = up_folded(ctx, m, p + ".feed_forward.w_1.weight", p + ".feed_forward.w_1.bias", p + ".norm1.weight",
                            p + ".norm1.bias", ff, d, ff, true, p + " feed-forward hidden layer", w1, b1)))
             return r;
         return up_folded(ctx, m, p + ".feed_forward.w_2.weight", "", p + ".feed_forward.norm.weight",
-                         p + ".feed_forward.norm.bias", d, ff, d, false, "", w2, b2);
+                         p + ".feed_forward.norm.bias", d, ff, d, false, "", w2, b2, c2);
     };
     W->layers.assign(cfg->num_blocks, DecLayerWeights{});
     for (int i = 0; i < cfg->num_blocks; ++i) {
         const std::string p = "decoder.decoders." + std::to_string(i);
         DecLayerWeights& L = W->layers[i];
-        if ((rc = ffn(p, &L.w1, &L.b1, &L.w2, &L.b2))) return fail(rc);
+        if ((rc = ffn(p, &L.w1, &L.b1, &L.w2, &L.b2, &L.c2))) return fail(rc);
         if ((rc = need(ctx, m, p + ".norm2.weight", {d}, &t, kWho)) || (rc = up_f32(ctx, t, &L.n2_g))) return fail(rc);
         if ((rc = need(ctx, m, p + ".norm2.bias", {d}, &t, kWho)) || (rc = up_f32(ctx, t, &L.n2_b))) return fail(rc);
         if ((rc = need(ctx, m, p + ".self_attn.fsmn_block.weight", {d, 1, ks}, &t, kWho))) return fail(rc);
@@ -166,7 +180,7 @@ extern "C" int32_t asrfe_load_decoder_weights(asrfe_ctx* ctx, const asrfe_decode
             return fail(rc);
         if ((rc = need(ctx, m, p + ".src_attn.linear_out.bias", {d}, &t, kWho)) || (rc = up_f32(ctx, t, &L.bo))) return fail(rc);
     }
-    if ((rc = ffn("decoder.decoders3.0", &W->w1_last, &W->b1_last, &W->w2_last, &W->b2_last))) return fail(rc);
+    if ((rc = ffn("decoder.decoders3.0", &W->w1_last, &W->b1_last, &W->w2_last, &W->b2_last, &W->c2_last))) return fail(rc);
     if ((rc = up_folded(ctx, m, "decoder.output_layer.weight", "decoder.output_layer.bias", "decoder.after_norm.weight",
                         "decoder.after_norm.bias", V, d, W->vocab_pad, false, "", &W->w_out, &W->b_out)))
         return fail(rc);
@@ -187,6 +201,8 @@ struct DecBuffers {
     uint16_t* h;      // [Md][512]
     uint16_t* f;      // [Md][ff]
     uint16_t* g;      // [Md][ff]
+    float* stats;     // [ff / 64][Md][2]: per 64-column strip of f, the sum and the sum of squares
+    float* row_norm;  // [Md][2]: mean and 1 / sqrt(var + eps) of f's rows
     uint16_t* q;      // [Md][512]
     uint16_t* att;    // [Md][512]
     float* logits;    // [Md][vocab_pad / 64] (value, column) pairs; [Md][vocab_pad] f32 when Md takes the latency plan
@@ -214,6 +230,8 @@ DecBuffers dec_carve(const asrfe_ctx* ctx, void* ws, int B, int Tp, int n_max) {
     b.h = reinterpret_cast<uint16_t*>(take(Md * 512 * 2));
     b.f = reinterpret_cast<uint16_t*>(take(Md * ff * 2));
     b.g = reinterpret_cast<uint16_t*>(take(Md * ff * 2));
+    b.stats = reinterpret_cast<float*>(take(Md * (ff / 64) * 8));
+    b.row_norm = reinterpret_cast<float*>(take(Md * 8));
     b.q = reinterpret_cast<uint16_t*>(take(Md * 512 * 2));
     b.att = reinterpret_cast<uint16_t*>(take(Md * 512 * 2));
     // without a logits buffer of the caller's the vocabulary projection keeps one (value, column) pair per 64-column
@@ -320,15 +338,30 @@ extern "C" int32_t asrfe_decoder_forward(asrfe_ctx* ctx, const float* enc_out, c
     if (hipMemcpyAsync(b.x, embeds, static_cast<size_t>(Md) * 512 * 4, hipMemcpyDeviceToDevice, s) != hipSuccess)
         return set_err(ctx, ASRFE_ERR_HIP, "asrfe_decoder_forward: copy of the embeddings failed");
 
-    auto feed_forward = [&](const uint16_t* w1, const float* b1, const uint16_t* w2, const float* b2) -> int32_t {
+    // Rows for the general GEMM: the hidden LayerNorm is applied behind the second product from row statistics that
+    // the first product's epilogue leaves (no pass over the [Md][ff] hidden layer in between).
+    const bool norm_after = Md > ctx->cfg.enc_small_batch_rows;
+    auto feed_forward = [&](const uint16_t* w1, const float* b1, const uint16_t* w2, const float* b2, const float* c2) -> int32_t {
         int32_t r;
         if ((r = launch_ln512(ctx, b.x, nullptr, nullptr, eps, Md, b.h, s))) return r;
+        if (norm_after) {
+            GemmParams g1{};
+            g1.A = b.h; g1.lda = 512; g1.W = w1; g1.ldw = 512; g1.bias = b1; g1.M = Md; g1.N = ff; g1.K = 512;
+            g1.out = b.f; g1.ldo = ff; g1.stat_out = b.stats;
+            if ((r = launch_gemm(ctx, g1, EPI_RELU_STAT, s))) return r;
+            if ((r = launch_row_stats_finish(ctx, b.stats, ff / 64, Md, eps, b.row_norm, s))) return r;
+            GemmParams g2{};
+            g2.A = b.f; g2.lda = ff; g2.W = w2; g2.ldw = ff; g2.bias = W.zero_bias; g2.M = Md; g2.N = 512; g2.K = ff;
+            g2.out = b.t; g2.ldo = 512; g2.ld32 = 512;
+            g2.stat_in = b.row_norm; g2.colsum = c2; g2.post_bias = b2;
+            return launch_gemm(ctx, g2, EPI_F32_NORM, s);
+        }
         if ((r = gemm(ctx, b.h, 512, w1, 512, b1, Md, ff, 512, b.f, ff, nullptr, EPI_BF16_RELU, s))) return r;
         if ((r = launch_ln_hidden(ctx, b.f, b.g, Md, ff, eps, s))) return r;
         return gemm(ctx, b.g, ff, w2, ff, b2, Md, 512, ff, b.t, 512, nullptr, EPI_F32_ADD, s);
     };
     for (const DecLayerWeights& L : W.layers) {
-        if ((rc = feed_forward(L.w1, L.b1, L.w2, L.b2))) return rc;
+        if ((rc = feed_forward(L.w1, L.b1, L.w2, L.b2, L.c2))) return rc;
         DecFsmnParams fp{};
         fp.t = b.t; fp.x = b.x; fp.gamma = L.n2_g; fp.beta = L.n2_b; fp.taps = L.taps; fp.token_num = token_num;
         fp.N = n_max; fp.eps = eps;
@@ -345,7 +378,7 @@ extern "C" int32_t asrfe_decoder_forward(asrfe_ctx* ctx, const float* enc_out, c
         if ((rc = gemm(ctx, b.att, 512, L.wo, 512, L.bo, Md, 512, 512, b.x, 512, b.x, EPI_F32_ADD, s))) return rc;
     }
     // closing block: feed-forward without residual, after_norm (folded into the output layer), vocabulary projection
-    if ((rc = feed_forward(W.w1_last, W.b1_last, W.w2_last, W.b2_last))) return rc;
+    if ((rc = feed_forward(W.w1_last, W.b1_last, W.w2_last, W.b2_last, W.c2_last))) return rc;
     if ((rc = launch_ln512(ctx, b.t, nullptr, nullptr, eps, Md, b.h, s))) return rc;
     // The caller does not ask for the logits and the rows take the general GEMM: its epilogue keeps the largest value
     // of every 64-column strip with its column instead of storing 554 MB (at 64 x 256 rows) for the arg-max to read back.

@@ -12,6 +12,7 @@ struct DecLayerWeights {
     // w_2, which thereby gets a bias
     uint16_t* w1; float* b1;    // [ff][512], [ff]
     uint16_t* w2; float* b2;    // [512][ff], [512]
+    float* c2;                  // [512]: row sums of w2 as stored (the GEMM applies the hidden LayerNorm after the product)
     float* n2_g; float* n2_b;   // norm2 scale / shift (applied in the FSMN kernel)
     float* taps;                // FSMN [11][512], tap-major
     uint16_t* wq; float* bq;    // [512][512] with norm3 folded in, [512]
@@ -26,6 +27,7 @@ struct DecoderWeights {
     float* zero_bias;                             // zeros, max(2048, vocab_pad) long
     std::vector<DecLayerWeights> layers;
     uint16_t* w1_last; float* b1_last; uint16_t* w2_last; float* b2_last;  // the feed-forward-only closing block
+    float* c2_last;
     uint16_t* w_out; float* b_out;                // [vocab_pad][512] with after_norm folded in, [vocab_pad]
     int vocab_pad;                                // vocab rounded up to a multiple of 256 (GEMM tile width)
 };

@@ -89,7 +89,7 @@ __device__ __forceinline__ void wave_lds_sync() {
 // 128-byte line, so each global access moves whole lines.  Only wave-level ordering is needed.
 template <int EPI, bool F16, int MS>
 __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, const f32x16 (&acc)[2][2 * MS], int m0, int n0, int wm, int wn,
-                                              int lane, char* es) {
+                                              int lane, char* es, const float (&rsum)[2 * MS][4], const float (&rsq)[2 * MS][4]) {
     const int l31 = lane & 31, h = lane >> 5;
     const int wr_row = l31 * 128, wr_sw = l31 & 7;   // this lane's row in the slab when writing
     const int rd_row = lane >> 3, rd_c = lane & 7;   // row (+ 8 i) and chunk when reading back
@@ -123,7 +123,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, const f32x16 
         }
         return;
     }
-    if constexpr (EPI == EPI_F32_ADD) {
+    if constexpr (EPI == EPI_F32_ADD || EPI == EPI_F32_NORM) {
 #pragma unroll
         for (int ns = 0; ns < 2; ++ns) {
             const int nb = n0 + wn * 64 + ns * 32;
@@ -136,11 +136,18 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, const f32x16 
                         make_float4(a[4 * g], a[4 * g + 1], a[4 * g + 2], a[4 * g + 3]);
                 wave_lds_sync();
                 const int mb = m0 + wm * (64 * MS) + ms * 32;
-#pragma unroll 2
+#pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     const int r = rd_row + 8 * i;
                     float4 v = *reinterpret_cast<const float4*>(es + r * 128 + ((rd_c ^ (r & 7)) << 4));
                     const int m = mb + r;
+                    if constexpr (EPI == EPI_F32_NORM) {
+                        const float mean = rsum[ms][i], rstd = rsq[ms][i];
+                        const float4 c4 = *reinterpret_cast<const float4*>(p.colsum + nb + rd_c * 4);
+                        const float4 d4 = *reinterpret_cast<const float4*>(p.post_bias + nb + rd_c * 4);
+                        v.x = (v.x - mean * c4.x) * rstd + d4.x; v.y = (v.y - mean * c4.y) * rstd + d4.y;
+                        v.z = (v.z - mean * c4.z) * rstd + d4.z; v.w = (v.w - mean * c4.w) * rstd + d4.w;
+                    }
                     if (m < p.M && live) {
                         const int n = nb + rd_c * 4;
                         if (p.add16) {
@@ -164,6 +171,10 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, const f32x16 
     } else {
 #pragma unroll
         for (int ms = 0; ms < 2 * MS; ++ms) {
+            // (EPI_RELU_STAT) this lane's 32 columns of row l31, as packed pairs: the epilogue runs with the matrix pipe
+            // idle, so its vector instructions are all exposed
+            typedef float v2f __attribute__((ext_vector_type(2)));
+            v2f s1[2] = {{0.0f, 0.0f}, {0.0f, 0.0f}}, s2[2] = {{0.0f, 0.0f}, {0.0f, 0.0f}};
 #pragma unroll
             for (int ns = 0; ns < 2; ++ns) {
                 const f32x16 a = acc[ns][ms];
@@ -172,9 +183,17 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, const f32x16 
                     float v[8];
 #pragma unroll
                     for (int e = 0; e < 8; ++e) v[e] = a[8 * gp + e];
-                    if constexpr (EPI == EPI_BF16_RELU) {
+                    if constexpr (EPI == EPI_BF16_RELU || EPI == EPI_RELU_STAT) {
 #pragma unroll
                         for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.0f);
+                    }
+                    if constexpr (EPI == EPI_RELU_STAT) {
+#pragma unroll
+                        for (int e = 0; e < 8; e += 2) {
+                            const v2f t = {v[e], v[e + 1]};
+                            asm("v_pk_add_f32 %0, %0, %1" : "+v"(s1[(e >> 1) & 1]) : "v"(t));
+                            asm("v_pk_fma_f32 %0, %1, %1, %0" : "+v"(s2[(e >> 1) & 1]) : "v"(t));
+                        }
                     }
                     uint32_t lo0 = pack_elem2<F16>(v[0], v[1]), lo1 = pack_elem2<F16>(v[2], v[3]);
                     uint32_t hi0 = pack_elem2<F16>(v[4], v[5]), hi1 = pack_elem2<F16>(v[6], v[7]);
@@ -187,6 +206,13 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, const f32x16 
             }
             wave_lds_sync();
             const int mb = m0 + wm * (64 * MS) + ms * 32;
+            if constexpr (EPI == EPI_RELU_STAT) {
+                float t1 = (s1[0].x + s1[0].y) + (s1[1].x + s1[1].y), t2 = (s2[0].x + s2[0].y) + (s2[1].x + s2[1].y);
+                t1 += __shfl_xor(t1, 32);
+                t2 += __shfl_xor(t2, 32);
+                if (h == 0 && mb + l31 < p.M && live)
+                    reinterpret_cast<float2*>(p.stat_out)[static_cast<int64_t>((n0 >> 6) + wn) * p.M + mb + l31] = make_float2(t1, t2);
+            }
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int r = rd_row + 8 * i;
@@ -306,6 +332,27 @@ __global__ __launch_bounds__(kGemmThreads) void gemm_bf16_kernel(const GemmParam
         }
     };
 
+    // EPI_F32_NORM: (mean, rstd) of the A operand's rows that this lane stores in the epilogue (row ms * 32 + (lane >> 3)
+    // + 8 i of the wave's share).  At half height they are requested when the tile begins, so that the loads fly behind
+    // the main loop; at full height the main loop has no registers to spare and they are requested in front of the
+    // epilogue.
+    float rsum[2 * MS][4], rsq[2 * MS][4];
+    auto gather_stats = [&](int tile) {
+        if constexpr (EPI == EPI_F32_NORM) {
+            const int tm_ = tile / p.n_tiles_n;
+#pragma unroll
+            for (int ms = 0; ms < 2 * MS; ++ms)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int m = tm_ * BM + wm * (64 * MS) + ms * 32 + (lane >> 3) + 8 * i;
+                    const float2 t2 = reinterpret_cast<const float2*>(p.stat_in)[m < p.M ? m : p.M - 1];
+                    rsum[ms][i] = t2.x;
+                    rsq[ms][i] = t2.y;
+                }
+        }
+    };
+    if constexpr (MS == 1) gather_stats(first_tile);
+
     u16x8 ra[MS][4];        // activation fragments [ms][s] of the current A half
     u16x8 rb[2][4];         // weight fragments [b][s]: rb[0] always holds B0, rb[1] always holds B1
     f32x16 acc[2][2 * MS];  // [b][a * MS + ms]
@@ -368,19 +415,69 @@ __global__ __launch_bounds__(kGemmThreads) void gemm_bf16_kernel(const GemmParam
         kt_in_tile += 2;
         if (kt_in_tile == nk) {  // this output tile is complete: store it while the next tile's loads fly
             const int tm = cur_tile / p.n_tiles_n, tn = cur_tile - tm * p.n_tiles_n;
-            gemm_epilogue<EPI, F16, MS>(p, acc, tm * BM, tn * BN, wm, wn, lane, smem + kRingBytes + wave * 4096);
+            if constexpr (MS == 2) gather_stats(cur_tile);
+            gemm_epilogue<EPI, F16, MS>(p, acc, tm * BM, tn * BN, wm, wn, lane, smem + kRingBytes + wave * 4096, rsum, rsq);
             kt_in_tile = 0;
             cur_tile += wgs_of_xcd;
-            if (g + 2 < n_kt) init_acc(acc, cur_tile);
+            if (g + 2 < n_kt) {
+                init_acc(acc, cur_tile);
+                if constexpr (MS == 1) gather_stats(cur_tile);
+            }
         }
     }
 #undef PHASE
 }
 
+// 32 rows per workgroup; thread (q, r) adds strips q, q + 8, .. of row r (a wave reads runs of 256 bytes), the eight
+// partial sums of a row meet in LDS
+__global__ __launch_bounds__(256) void row_stats_finish_kernel(const float2* __restrict__ partial, int n_strips, int M, float eps,
+                                                               float2* __restrict__ row_norm) {
+    __shared__ float2 part[8][32];
+    const int r = threadIdx.x & 31, q = threadIdx.x >> 5;
+    const int m = blockIdx.x * 32 + r;
+    const int mc = m < M ? m : M - 1;
+    float s1 = 0.0f, s2 = 0.0f;
+#pragma unroll 4
+    for (int j = q; j < n_strips; j += 8) {
+        const float2 t = partial[static_cast<int64_t>(j) * M + mc];
+        s1 += t.x;
+        s2 += t.y;
+    }
+    part[q][r] = make_float2(s1, s2);
+    __syncthreads();
+    if (q == 0 && m < M) {
+#pragma unroll
+        for (int k = 1; k < 8; ++k) {
+            s1 += part[k][r].x;
+            s2 += part[k][r].y;
+        }
+        const float inv = 1.0f / static_cast<float>(64 * n_strips);
+        const float mean = s1 * inv;
+        row_norm[m] = make_float2(mean, 1.0f / sqrtf(fmaxf(s2 * inv - mean * mean, 0.0f) + eps));
+    }
+}
+
+int32_t launch_row_stats_finish(asrfe_ctx* ctx, const float* partial, int n_strips, int M, float eps, float* row_norm, hipStream_t s) {
+    if (M <= 0) return ASRFE_OK;
+    hipLaunchKernelGGL(row_stats_finish_kernel, dim3((M + 31) / 32), dim3(256), 0, s, reinterpret_cast<const float2*>(partial),
+                       n_strips, M, eps, reinterpret_cast<float2*>(row_norm));
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return set_err(ctx, ASRFE_ERR_HIP, std::string("row_stats_finish launch: ") + hipGetErrorString(e));
+    return ASRFE_OK;
+}
+
 // The dynamic-LDS limit of a kernel is a per-device attribute: asrfe_create calls this with the context's device
 // current, before any compute call can run.
 int32_t prepare_gemm(asrfe_ctx* ctx) {
-    const void* fns[16] = {reinterpret_cast<const void*>(gemm_bf16_kernel<EPI_ARGMAX, false, 2>),
+    const void* fns[24] = {reinterpret_cast<const void*>(gemm_bf16_kernel<EPI_RELU_STAT, false, 2>),
+                           reinterpret_cast<const void*>(gemm_bf16_kernel<EPI_RELU_STAT, true, 2>),
+                           reinterpret_cast<const void*>(gemm_bf16_kernel<EPI_RELU_STAT, false, 1>),
+                           reinterpret_cast<const void*>(gemm_bf16_kernel<EPI_RELU_STAT, true, 1>),
+                           reinterpret_cast<const void*>(gemm_bf16_kernel<EPI_F32_NORM, false, 2>),
+                           reinterpret_cast<const void*>(gemm_bf16_kernel<EPI_F32_NORM, true, 2>),
+                           reinterpret_cast<const void*>(gemm_bf16_kernel<EPI_F32_NORM, false, 1>),
+                           reinterpret_cast<const void*>(gemm_bf16_kernel<EPI_F32_NORM, true, 1>),
+                           reinterpret_cast<const void*>(gemm_bf16_kernel<EPI_ARGMAX, false, 2>),
                            reinterpret_cast<const void*>(gemm_bf16_kernel<EPI_ARGMAX, true, 2>),
                            reinterpret_cast<const void*>(gemm_bf16_kernel<EPI_ARGMAX, false, 1>),
                            reinterpret_cast<const void*>(gemm_bf16_kernel<EPI_ARGMAX, true, 1>),
@@ -407,6 +504,8 @@ int32_t launch_gemm(asrfe_ctx* ctx, const GemmParams& pin, int epi, hipStream_t 
     if (p.M <= 0) return ASRFE_OK;
     if (p.N % BN != 0 || p.K % (2 * BK) != 0 || p.K <= 0 || p.lda % 8 != 0 || p.ldw % 8 != 0 || (p.ldo % 8 != 0 && epi != EPI_ARGMAX))
         return set_err(ctx, ASRFE_ERR_SHAPE, "gemm: N must be a multiple of 256, K of 128, leading dims of 8");
+    if ((epi == EPI_RELU_STAT && !p.stat_out) || (epi == EPI_F32_NORM && (!p.stat_in || !p.colsum || !p.post_bias)))
+        return set_err(ctx, ASRFE_ERR_BAD_ARG, "gemm: row statistics need their buffers");
     if (epi == EPI_ARGMAX && p.ldo < p.N / 64) return set_err(ctx, ASRFE_ERR_SHAPE, "gemm: a row of the arg-max output holds N / 64 pairs");
     p.n_tiles_n = p.N / BN;
     // Half-height tiles when they still fit the chip in one round and full-height tiles would leave CUs idle
@@ -433,6 +532,8 @@ int32_t launch_gemm(asrfe_ctx* ctx, const GemmParams& pin, int epi, hipStream_t 
         case EPI_BF16_RELU: LAUNCH_GEMM(EPI_BF16_RELU); break;
         case EPI_F32_ADD: LAUNCH_GEMM(EPI_F32_ADD); break;
         case EPI_ARGMAX: LAUNCH_GEMM(EPI_ARGMAX); break;
+        case EPI_RELU_STAT: LAUNCH_GEMM(EPI_RELU_STAT); break;
+        case EPI_F32_NORM: LAUNCH_GEMM(EPI_F32_NORM); break;
         default: return set_err(ctx, ASRFE_ERR_BAD_ARG, "gemm: bad epilogue");
     }
 #undef LAUNCH_GEMM
