@@ -80,6 +80,13 @@ def hbm_traffic(kernel):
     return None if k is None else k["fetch_bytes"] + k["write_bytes"]
 
 
+def side_traffic(program):
+    """HBM bytes per pass of a whole side program ("decoder", "vocoder": tools/profile_side.sh) from the same file."""
+    d, _ = counter_profile()
+    k = None if d is None else d.get("side", {}).get(program)
+    return None if k is None else k["fetch_bytes"] + k["write_bytes"]
+
+
 def mfma_pipe_busy(kernel):
     """Matrix-pipe busy cycles over kernel cycles (SQ_VALU_MFMA_BUSY_CYCLES per SIMD / GRBM_GUI_ACTIVE per XCD) from the
     same file; a profile-time figure, not measured in this run.  None if there is none."""
@@ -480,7 +487,7 @@ def main():
             "kernel": "CIF predictor + 16 decoder blocks + vocabulary projection with arg-max epilogue, 64 x 256 token rows "
                       "over 64 x 500 encoder frames (about 165 launches; the products run on gemm_bf16_kernel)",
             "bound": "mfma", "achieved": dec_flop / t_head / 1e12, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
-            "frac": dec_flop / t_head / 1e12 / MFMA_BF16_PEAK_TFLOPS, "traffic": None,
+            "frac": dec_flop / t_head / 1e12 / MFMA_BF16_PEAK_TFLOPS, "traffic": side_traffic("decoder"),
             "flop_per_step": dec_flop,
             "note": "all products of one step over the step's wall time (memory-bound passes included in the time)",
         }
@@ -505,7 +512,7 @@ def main():
             "workload": "HiFi-GAN generator (512 channels, rates 8-8-2-2, residual kernels 3-7-11), 128 x 94 mel frames -> 128 x 24064 samples",
             "ms_per_batch": 1e3 * t_voc, "audio_s_per_s": 128 * 94 * 256 / 24000.0 / t_voc,
             "roofline": {"bound": "mfma", "achieved": vfl / t_voc / 1e12, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": vfl / t_voc / 1e12 / MFMA_BF16_PEAK_TFLOPS, "traffic": None,
+                         "frac": vfl / t_voc / 1e12 / MFMA_BF16_PEAK_TFLOPS, "traffic": side_traffic("vocoder"),
                          "note": "all convolutions of one batch (implicit-GEMM FLOPs) over the whole forward's wall time"},
         }
         del voc, mel

@@ -3,7 +3,7 @@
 of tools/pmc_fbank_traffic.sh): mean per launch of FETCH_SIZE, WRITE_SIZE, SQ_VALU_MFMA_BUSY_CYCLES and GRBM_GUI_ACTIVE
 per kernel, with the hash of the kernel sources the run was made with (tools/buildtag.py).
 
-    python tools/make_traffic_json.py <tag> <build description> <profile_round dir> [<fbank traffic dir>]
+    python tools/make_traffic_json.py <tag> <build description> <profile_round dir> [<fbank traffic dir> [<profile_side dir>]]
 
 FETCH_SIZE and WRITE_SIZE are reported in KiB; on gfx950 FETCH_SIZE tallies the 128-byte requests of 16-byte-per-lane
 streaming loads at 64 bytes and is doubled here, WRITE_SIZE is taken as it is."""
@@ -63,6 +63,22 @@ def main():
                 out["kernels"]["frontend_fused" if fused else "fbank"] = {
                     "fetch_bytes": int(c["FETCH_SIZE"] * 1024 * 2), "write_bytes": int(c["WRITE_SIZE"] * 1024),
                     "note": k[:90] + ", 256 x 30 s (tools/pmc_fbank_traffic.sh)"}
+    if len(sys.argv) > 5:
+        # tools/profile_side.sh: whole programs (decoder head, vocoder), 4 passes each; every asrfe kernel's launches added up
+        out["side"] = {}
+        for prog in ("dec", "voc"):
+            tot = {}
+            for cname, suffix in (("FETCH_SIZE", "f"), ("WRITE_SIZE", "w")):
+                s = 0.0
+                for f in sorted(glob.glob(os.path.join(sys.argv[5], "**", f"{prog}_{suffix}_counter_collection.csv"), recursive=True)):
+                    for r in csv.DictReader(open(f)):
+                        if "asrfe" in r["Kernel_Name"] and r["Counter_Name"] == cname:
+                            s += float(r["Counter_Value"])
+                tot[cname] = s
+            if tot["FETCH_SIZE"] > 0 and tot["WRITE_SIZE"] > 0:
+                out["side"]["decoder" if prog == "dec" else "vocoder"] = {
+                    "fetch_bytes": int(tot["FETCH_SIZE"] * 1024 * 2 / 4), "write_bytes": int(tot["WRITE_SIZE"] * 1024 / 4),
+                    "note": "per pass of tools/%s_bench.py (all its kernels), 4 passes per counter run" % ("decoder" if prog == "dec" else "vocoder")}
     path = os.path.join(ROOT, "profiles", f"{tag}_hbm_traffic.json")
     json.dump(out, open(path, "w"), indent=1)
     print(json.dumps(out, indent=1))
