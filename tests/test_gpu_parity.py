@@ -424,12 +424,14 @@ def test_encoder_other_feed_forward_widths(pkg, ff, small_rows):
     assert err <= ENC_TOL, (ff, err)
 
 
-def test_post_attention_kernel_vs_fp64(pkg):
+def test_post_attention_kernel_vs_fp64(pkg, monkeypatch):
     """The fused kernel behind attention (output projection + FSMN + residual, norm2, feed-forward, next-layer
     normalisation or next-layer QKV projection) on its own, through the debug hook: x_out within 2e-3, the normalised
     y within 1e-2 and the next layer's q, k, v within 2e-2 of an fp64 evaluation on the same 16-bit-rounded inputs;
     row counts around the 32 / 128 row tile edges."""
     import ctypes as C
+    # (the 32x32x16 form of the kernel, which serves every launch plan; a context's weight stream is packed for one form)
+    monkeypatch.setenv("ASRFE_MFMA16", "0")
     cfg = so.SanmConfig(num_blocks=2)
     sd = _trained_like(so.make_state_dict(cfg, seed=4, dtype=torch.float32), seed=6)
     enc = pkg.SANMEncoder(num_blocks=2)
@@ -490,6 +492,71 @@ def test_post_attention_kernel_vs_fp64(pkg):
         assert float((qkv4.double() - qref).abs().max()) <= 2e-2, (m, with_x)
 
 
+@pytest.mark.parametrize("dtype", ["float16", "bfloat16"])
+def test_post_attention_kernel_16x16x32_vs_fp64(pkg, monkeypatch, dtype):
+    """The same kernel on v_mfma_f32_16x16x32 (the throughput plan's default): tiled residual stream in ITS register
+    order (per 32-row group and 32-column block four runs of 1 KiB: run 2 a + mh = columns 16 a + 4 q .. + 3 of rows
+    16 mh + c for lane 16 q + c), x_out alone (row-major out: the last layer) and x_out tiled with the next layer's
+    q, k, v; against fp64 on the same 16-bit-rounded inputs, and against the 32x32x16 form on the same inputs."""
+    import ctypes as C
+    cfg = so.SanmConfig(num_blocks=2)
+    sd = _trained_like(so.make_state_dict(cfg, seed=4, dtype=torch.float32), seed=6)
+    monkeypatch.setenv("ASRFE_MFMA16", "0")
+    old = pkg.SANMEncoder(num_blocks=2, compute_dtype=dtype)
+    old.load_state_dict(sd)
+    monkeypatch.setenv("ASRFE_MFMA16", "1")
+    enc = pkg.SANMEncoder(num_blocks=2, compute_dtype=dtype)
+    enc.load_state_dict(sd)
+    stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    w = {k: v.double().cuda() for k, v in sd.items()}
+    p = "encoders0.0."
+    t16 = torch.float16 if dtype == "float16" else torch.bfloat16
+    tol_x, tol_q = (2e-3, 2e-2) if dtype == "float16" else (1.6e-2, 1.6e-1)
+    for m, with_x in [(1, True), (31, False), (32, True), (129, True), (257, False), (1000, True)]:
+        gen = torch.Generator().manual_seed(m)
+        att = (torch.randn(m, 512, generator=gen) * 0.5).to(t16).cuda()
+        fsmn = (torch.randn(m, 512, generator=gen) * 0.5).to(t16).cuda()
+        x = (torch.randn(m, 512, generator=gen) * 2.0 + 0.3).cuda()
+        xm = att.double() @ w[p + "self_attn.linear_out.weight"].T + w[p + "self_attn.linear_out.bias"] + fsmn.double()
+        if with_x:
+            xm = xm + x.double()
+        hh = torch.nn.functional.layer_norm(xm, (512,), w[p + "norm2.weight"], w[p + "norm2.bias"], 1e-12)
+        hh = torch.relu(hh @ w[p + "feed_forward.w_1.weight"].T + w[p + "feed_forward.w_1.bias"])
+        ref = xm + hh @ w[p + "feed_forward.w_2.weight"].T + w[p + "feed_forward.w_2.bias"]
+        n1 = torch.nn.functional.layer_norm(ref, (512,), w["encoders.0.norm1.weight"], w["encoders.0.norm1.bias"], 1e-12)
+        qref = n1 @ w["encoders.0.self_attn.linear_q_k_v.weight"].T + w["encoders.0.self_attn.linear_q_k_v.bias"]
+        mp = (m + 127) // 128 * 128
+        xp = torch.zeros(mp, 512, device="cuda")
+        xp[:m] = x
+        # row-major [group][mh][c][nt][a][q][e] -> [group][nt][a][mh][q][c][e]
+        xt = xp.view(mp // 32, 2, 16, 16, 2, 4, 4).permute(0, 3, 4, 1, 5, 2, 6).contiguous()
+        xo = torch.empty_like(x)
+        enc.ctx.check(enc.ctx.lib.asrfe_debug_post_attn(enc.ctx.handle, 0, att.data_ptr(), fsmn.data_ptr(),
+                                                        xt.data_ptr() if with_x else None, xo.data_ptr(), None, None, m, 512, stream))
+        assert float((xo.double() - ref).abs().max()) <= tol_x, (m, with_x)
+        xo_t = torch.full((mp // 32, 16, 2, 2, 4, 16, 4), float("nan"), device="cuda")
+        qkv = torch.empty(m, 1536, dtype=t16, device="cuda")
+        enc.ctx.check(enc.ctx.lib.asrfe_debug_post_attn(enc.ctx.handle, 0, att.data_ptr(), fsmn.data_ptr(),
+                                                        xt.data_ptr() if with_x else None, xo_t.data_ptr(), None, qkv.data_ptr(), m, 512,
+                                                        stream))
+        assert torch.equal(xo, xo_t.permute(0, 3, 5, 1, 2, 4, 6).reshape(mp, 512)[:m]), (m, with_x)
+        assert float((qkv.double() - qref).abs().max()) <= tol_q, (m, with_x)
+        # the other form on the same inputs (its own tiled order): the same sums in another order
+        xt_old = xp.view(mp // 32, 32, 16, 4, 2, 4).permute(0, 2, 3, 4, 1, 5).contiguous()
+        xo_old = torch.empty_like(x)
+        old.ctx.check(old.ctx.lib.asrfe_debug_post_attn(old.ctx.handle, 0, att.data_ptr(), fsmn.data_ptr(),
+                                                        xt_old.data_ptr() if with_x else None, xo_old.data_ptr(), None, None, m, 512,
+                                                        stream))
+        assert float((xo - xo_old).abs().max()) <= (1e-3 if dtype == "float16" else 1.6e-2), (m, with_x)
+    # what this form does not serve is refused, not computed wrongly
+    y = torch.empty(8, 512, dtype=t16, device="cuda")
+    rc = enc.ctx.lib.asrfe_debug_post_attn(enc.ctx.handle, 0, att.data_ptr(), fsmn.data_ptr(), None, xo.data_ptr(), y.data_ptr(),
+                                           None, 8, 0, stream)
+    assert rc == -1
+    with pytest.raises(pkg.AsrfeError, match="tiled residual stream"):
+        enc.ctx.check(rc)
+
+
 def test_fused_and_unfused_encoder_paths_agree(pkg, monkeypatch):
     """Launch plans for the same layers: the throughput plan (the post-attention kernel also projects the next
     layer's q, k, v), ASRFE_SEPARATE_QKV=1 (it writes the normalised rows and every layer launches its own projection),
@@ -518,8 +585,10 @@ def test_fused_and_unfused_encoder_paths_agree(pkg, monkeypatch):
     assert float((outs[0] - outs[3]).abs().max()) <= 4e-3
     assert not torch.equal(outs[0], outs[3])  # the latency plan really is another sequence of kernels
     # ASRFE_ROW_MAJOR_X=1 keeps the residual stream row-major between the post-attention launches (the throughput plan
-    # otherwise hands it on in the kernel's register order and adds it at another point of the same sum)
-    assert float((outs[0] - outs[4]).abs().max()) <= 2e-3
+    # otherwise hands it on in the kernel's register order and adds it at another point of the same sum); that plan also
+    # takes the 32x32x16 form of the kernel, whose products accumulate in another order than the default 16x16x32 form
+    assert float((outs[0] - outs[4]).abs().max()) <= 4e-3
+    assert not torch.equal(outs[0], outs[4])
 
 
 def test_engine_streams_give_identical_results(pkg):

@@ -173,6 +173,9 @@ extern "C" int32_t asrfe_create(const asrfe_config* cfg, asrfe_ctx** out) {
         ctx->separate_qkv = e && e[0] == '1';
         e = std::getenv("ASRFE_ROW_MAJOR_X");
         ctx->row_major_x = e && e[0] == '1';
+        e = std::getenv("ASRFE_MFMA16");
+        ctx->mfma16 = !(e && e[0] == '0') && !ctx->unfused_ffn && !ctx->separate_qkv && !ctx->row_major_x &&
+                      cfg->enc_num_blocks > 1 && cfg->enc_linear_units <= kPostAttnQkvMaxFf;
     }
     // the latency plan's second feed-forward product takes linear_units in 512-deep steps up to 3072
     ctx->small_rows = (cfg->enc_linear_units % 512 == 0 && cfg->enc_linear_units <= 3072 && !ctx->unfused_ffn) ? cfg->enc_small_batch_rows : 0;
@@ -316,7 +319,7 @@ extern "C" int32_t asrfe_create(const asrfe_config* cfg, asrfe_ctx** out) {
     if ((rc = upload(ctx, inv, &ctx->pe_inv))) return fail(rc);
 
     // per-device kernel attributes (dynamic LDS above 64 KiB), set here so that no compute call ever has to
-    if ((rc = prepare_gemm(ctx)) || (rc = prepare_post_attn(ctx)) || (rc = prepare_static_scratch(ctx)))
+    if ((rc = prepare_gemm(ctx)) || (rc = prepare_post_attn(ctx)) || (rc = prepare_post_attn16(ctx)) || (rc = prepare_static_scratch(ctx)))
         return fail(rc);
 
     *out = ctx;
@@ -396,7 +399,13 @@ static int32_t up_layer_stream(asrfe_ctx* ctx, const HostTensor* wo, const HostT
     const int64_t ff = w1->shape[0], d = w1->shape[1];
     const bool f16 = ctx->cfg.enc_compute_dtype == ASRFE_DT_F16;
     auto cvt = [&](float w) { return f16 ? f16_rne(w) : bf16_rne(w); };
-    auto swap23 = [](int64_t c) { return (c & ~int64_t{12}) | ((c & 4) << 1) | ((c & 8) >> 1); };
+    // k order of an operand that is fed from accumulator registers.  32x32x16 kernel: bits 2 and 3 swapped inside every
+    // 16.  16x16x32 kernel: stored position 8 q + i of every block of 32 holds column 16 (i >> 2) + 4 q + (i & 3).
+    const bool m16 = ctx->mfma16;
+    auto swap23 = [m16](int64_t c) {
+        if (m16) return (c & ~int64_t{31}) | (((c >> 2) & 1) << 4) | (((c >> 3) & 3) << 2) | (c & 3);
+        return (c & ~int64_t{12}) | ((c & 4) << 1) | ((c & 8) >> 1);
+    };
     const int64_t nch = ff / 64;
     std::vector<uint16_t> v(static_cast<size_t>((4 + nch + (wqkv ? 13 : 0)) * 8 * 8192), 0);
     for (int64_t c = 0; c < 4; ++c)
@@ -747,6 +756,7 @@ extern "C" int32_t asrfe_debug_post_attn(asrfe_ctx* ctx, int32_t layer, const vo
     }
     f.eps = ctx->cfg.enc_ln_eps; f.M = m; f.ff = ctx->cfg.enc_linear_units; f.flags = flags & ~512;
     f.tiled = (flags & 512) ? 1 : 0;
+    if (ctx->mfma16) return launch_post_attn16(ctx, f, static_cast<hipStream_t>(stream));  // (refuses what is not tiled)
     return launch_post_attn(ctx, f, static_cast<hipStream_t>(stream));
 }
 

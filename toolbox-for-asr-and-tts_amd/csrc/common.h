@@ -85,6 +85,9 @@ struct asrfe_ctx {
     bool unfused_ffn;  // ASRFE_UNFUSED_FFN=1 in the environment: LayerNorm + two GEMM launches instead of the fused kernel
     bool separate_qkv;  // ASRFE_SEPARATE_QKV=1: every layer launches its own QKV projection
     bool row_major_x;   // ASRFE_ROW_MAJOR_X=1: the residual stream stays row-major between post-attention launches
+    bool mfma16;        // the post-attention kernel on v_mfma_f32_16x16x32 (post_attn16.hip): the weight stream is packed
+                        // for it when the weights are loaded.  ASRFE_MFMA16=0 keeps the 32x32x16 kernel; so does any plan
+                        // that needs the row-major residual stream or a layer without the fused QKV projection
     int small_rows;     // encoder calls of at most this many rows take the latency plan (0: never)
     std::vector<asrfe::LayerWeights> layers;
     float* after_g;

@@ -164,7 +164,7 @@ int32_t encoder_forward(asrfe_ctx* ctx, const float* feats, const int32_t* lens,
                 qkv_ready = true;
             }
             f.eps = c.enc_ln_eps; f.M = M; f.ff = ff;
-            { ProfScope ps(ctx, PK_FFN_FUSED, s); rc = launch_post_attn(ctx, f, s); }
+            { ProfScope ps(ctx, PK_FFN_FUSED, s); rc = ctx->mfma16 ? launch_post_attn16(ctx, f, s) : launch_post_attn(ctx, f, s); }
             if (rc) return rc;
             continue;
         }

@@ -79,6 +79,10 @@ struct FfnParams {
     long long* trace;      // timing build only: cycle-counter stamps of one wave (flags bit 8)
 };
 int32_t launch_post_attn(asrfe_ctx* ctx, const FfnParams& p, hipStream_t s);
+// the same kernel on v_mfma_f32_16x16x32 (post_attn16.hip): tiled residual stream only (qkv output or x_out alone), and a
+// weight stream whose accumulator-fed operands are packed in ITS k order (asrfe_ctx::mfma16)
+int32_t launch_post_attn16(asrfe_ctx* ctx, const FfnParams& p, hipStream_t s);
+int32_t prepare_post_attn16(asrfe_ctx* ctx);
 int32_t prepare_post_attn(asrfe_ctx* ctx);  // per-device kernel attributes; called by asrfe_create
 
 }  // namespace asrfe
