@@ -25,3 +25,18 @@ def test_output_projection_waits_match_the_issue_order():
         assert cq.check(path) == []
     finally:
         shutil.rmtree(os.path.dirname(path), ignore_errors=True)
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="needs hipcc to generate the kernel's assembly")
+def test_output_projection_waits_of_the_16x16x32_kernel():
+    """The same queue in the kernel's 16x16x32 form (32 MFMAs per weight piece)."""
+    from tools import check_vm_queue as cq
+
+    path = cq.generate_asm("post_attn16.hip")
+    try:
+        ev = cq.events(path, cq.KERNEL16)
+        assert sum(e[0] == "X" for e in ev) == 12 + 13 * 4
+        assert sum(1 for l in open(path) if "v_mfma_f32_16x16x32_f16" in l) >= 2048
+        assert cq.check(path, cq.KERNEL16, 32) == []
+    finally:
+        shutil.rmtree(os.path.dirname(path), ignore_errors=True)

@@ -30,6 +30,9 @@ namespace {
 #ifndef ASRFE_FFN_TIMING
 #define ASRFE_FFN_TIMING 0
 #endif
+#ifndef ASRFE_FFN_ABLATE
+#define ASRFE_FFN_ABLATE 0
+#endif
 
 typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
 
@@ -538,6 +541,9 @@ __global__ __launch_bounds__(kFfnThreads) void post_attn16_kernel(const FfnParam
             mma(rc, IC<F + 8>{});
             if constexpr (!((LAST || TO_PROJ) && R == 7)) wf[F] = frag(IC<((R + 1) & 7)>{}, f);
             if constexpr ((F & 1) == 0) {
+#if ASRFE_FFN_ABLATE & 2  // timing experiment: the feed-forward's weight pieces are not requested (wrong results)
+                return;
+#endif
                 if constexpr (R == 0) stage_quarter(IC<7>{}, cb0, F >> 1);
                 else if constexpr (!LAST) stage_quarter(IC<(R + 7) & 7>{}, cb1, F >> 1);
             }

@@ -20,13 +20,15 @@ import tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 KERNEL = "_ZN5asrfe16post_attn_kernelILb1ELi2ELb1EEEvNS_9FfnParamsE"  # <fp16, qkv output, tiled residual stream>
+# the same kernel on v_mfma_f32_16x16x32 (csrc/post_attn16.hip): the same queue, 32 MFMAs per piece instead of 16
+KERNEL16 = "_ZN5asrfe12_GLOBAL__N_118post_attn16_kernelILb1ELi2EEEvNS_9FfnParamsE"
 
 
-def generate_asm():
+def generate_asm(source="post_attn.hip"):
     csrc = os.path.join(ROOT, "toolbox-for-asr-and-tts_amd", "csrc")
-    out = os.path.join(tempfile.mkdtemp(), "post_attn.s")
+    out = os.path.join(tempfile.mkdtemp(), source.replace(".hip", ".s"))
     subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-I" + os.path.join(ROOT, "include"),
-                           "-I" + csrc, "-S", "--cuda-device-only", "-o", out, os.path.join(csrc, "post_attn.hip")],
+                           "-I" + csrc, "-S", "--cuda-device-only", "-o", out, os.path.join(csrc, source)],
                           stderr=subprocess.DEVNULL)
     return out
 
@@ -59,8 +61,10 @@ def events(path, kernel=KERNEL):
     return ev
 
 
-def check(path):
-    ev = events(path)
+def check(path, kernel=KERNEL, mp=16):
+    """mp: MFMAs per weight piece (16 for the 32x32x16 kernel, 32 for the 16x16x32 one)."""
+    ev = events(path, kernel)
+    half = mp // 2
     errors = []
     ops = [e for e in ev if e[0] != "W"]           # the queue, in issue order
     pre = [e for e in ops if e[1] == 0]            # issued before the first MFMA
@@ -73,7 +77,7 @@ def check(path):
         last_w[w] = n_pre - 1 - 4 * (7 - w)
     for j in range(32):
         # (the second half of piece j: behind its MFMAs 9 .. 16; the first half issues no loads)
-        idx = [k for k, e in enumerate(ops) if 16 * j + 9 <= e[1] <= 16 * j + 16]
+        idx = [k for k, e in enumerate(ops) if mp * j + half + 1 <= e[1] <= mp * j + mp]
         d = [k for k in idx if ops[k][0] == "D"]
         x = [k for k in idx if ops[k][0] == "X"]
         want_d = 4 if j >= 1 else 0
@@ -90,8 +94,8 @@ def check(path):
     waits = {}
     for e in ev:
         if e[0] == "W":
-            if e[1] >= 8 and (e[1] - 8) % 16 == 0 and e[1] < 512:
-                waits[(e[1] - 8) // 16] = (pos, e[2])
+            if e[1] >= half and (e[1] - half) % mp == 0 and e[1] < 32 * mp:
+                waits[(e[1] - half) // mp] = (pos, e[2])
         else:
             pos += 1
     for i in range(32):
@@ -116,8 +120,11 @@ def check(path):
 
 
 def main():
-    path = sys.argv[1] if len(sys.argv) > 1 else generate_asm()
-    errors = check(path)
+    errors = []
+    if len(sys.argv) > 1:
+        errors = check(sys.argv[1])
+    else:
+        errors = check(generate_asm()) + ["16x16x32 kernel: " + e for e in check(generate_asm("post_attn16.hip"), KERNEL16, 32)]
     for e in errors:
         print("MISMATCH:", e)
     print("post-attention output projection: 32 mid-piece waits checked against the issue order," if not errors else "",

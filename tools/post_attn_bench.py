@@ -140,14 +140,15 @@ def main():
         print(f"reference gemm [{m} x 512] x [512 x 2048]: {1e3 * e0.elapsed_time(e1) / args.iters:7.1f} us")
 
     if any(f & 256 for f in args.flags):  # timing build: per-phase cycle stamps of one wave
-        tr = torch.zeros(64, dtype=torch.int64, device=dev)
-        for _ in range(3):
-            ctx.check(lib.asrfe_debug_post_attn(ctx.handle, 0, att.data_ptr(), fsmn.data_ptr(), x.data_ptr(), x.data_ptr(),
-                                                tr.data_ptr(), qkv.data_ptr(), m, 256 | TILED, stream))
-        torch.cuda.synchronize()
-        t = [v for v in tr.cpu().tolist() if v]
-        names = ["prologue", "out-proj", "LayerNorm", "feed-forward", "x_out + fragments", "q pass", "k pass", "v pass", "stores"]
-        print("phase cycles:", {n: b - a for n, a, b in zip(names, t, t[1:])}, "total", t[-1] - t[0])
+        for fl in [f for f in args.flags if f & 256]:
+            tr = torch.zeros(64, dtype=torch.int64, device=dev)
+            for _ in range(3):
+                ctx.check(lib.asrfe_debug_post_attn(ctx.handle, 0, att.data_ptr(), fsmn.data_ptr(), x.data_ptr(), x.data_ptr(),
+                                                    tr.data_ptr(), qkv.data_ptr(), m, fl | TILED, stream))
+            torch.cuda.synchronize()
+            t = [v for v in tr.cpu().tolist() if v]
+            names = ["prologue", "out-proj", "LayerNorm", "feed-forward", "x_out + fragments", "q pass", "k pass", "v pass", "stores"]
+            print(f"flags {fl} phase cycles:", {n: b - a for n, a, b in zip(names, t, t[1:])}, "total", t[-1] - t[0])
         return
     ref_gemm()
     for flags in args.flags * args.repeat:
