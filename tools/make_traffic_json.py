@@ -18,7 +18,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from tools.buildtag import ROOT, csrc_tag  # noqa: E402
 
 # (the post-attention variant that also projects the next layer's q, k, v: 49 of a step's 50 launches)
-KERNELS = {"post_attn": "post_attn_kernel<true, 2, true>", "attention": "attn_kernel", "gemm_qkv": "gemm_bf16_kernel"}
+KERNELS = {"post_attn": "post_attn16_kernel<true, 2>", "attention": "attn_kernel", "gemm_qkv": "gemm_bf16_kernel"}
 
 
 def means(d):
