@@ -145,10 +145,16 @@ namespace {
 struct VocBuffers {
     uint16_t* mel16;  // [B][T][n_mels]
     uint16_t* a[4];   // 16-bit activations: stage input, convolution scratch, ping, pong
-    float* r[3];      // f32: stage residual stream, ping, pong
-    float* out[4];    // f32: the output of each of a stage's residual blocks
+    void* r[3];       // residual stream (f32, or the 16-bit operand type: voc_res16): stage's, ping, pong
+    void* out[4];     // the same type: the output of each of a stage's residual blocks
     int64_t bytes;
 };
+// fp16 contexts keep the generator's residual stream in fp16: every consumer of it rounds to fp16 anyway (a convolution's
+// operand) or adds at most three convolution outputs to it before the next rounding; ASRFE_VOC_RES32=1 keeps f32
+bool voc_res16(const asrfe_ctx* ctx) {
+    static const bool off = [] { const char* e = getenv("ASRFE_VOC_RES32"); return e && atoi(e) != 0; }();
+    return ctx->cfg.enc_compute_dtype == ASRFE_DT_F16 && !off;
+}
 VocBuffers voc_carve(const asrfe_ctx* ctx, void* ws, int B, int T) {
     const VocoderWeights& W = *ctx->voc;
     int64_t worst = static_cast<int64_t>(B) * T * W.cfg.initial_channel, len = T, ch = W.cfg.initial_channel;
@@ -167,8 +173,9 @@ VocBuffers voc_carve(const asrfe_ctx* ctx, void* ws, int B, int T) {
     VocBuffers b;
     b.mel16 = reinterpret_cast<uint16_t*>(take(static_cast<int64_t>(B) * T * W.cfg.n_mels * 2));
     for (int i = 0; i < 4; ++i) b.a[i] = reinterpret_cast<uint16_t*>(take(worst * 2));
-    for (int i = 0; i < 3; ++i) b.r[i] = reinterpret_cast<float*>(take(worst * 4));
-    for (int i = 0; i < 4; ++i) b.out[i] = i < W.cfg.n_resblocks ? reinterpret_cast<float*>(take(worst * 4)) : nullptr;
+    const int64_t rs = voc_res16(ctx) ? 2 : 4;
+    for (int i = 0; i < 3; ++i) b.r[i] = take(worst * rs);
+    for (int i = 0; i < 4; ++i) b.out[i] = i < W.cfg.n_resblocks ? take(worst * rs) : nullptr;
     b.bytes = off;
     return b;
 }
@@ -198,9 +205,11 @@ extern "C" int32_t asrfe_vocoder_forward(asrfe_ctx* ctx, const float* mel, int32
     int32_t rc;
     if ((rc = launch_mel_to_ntc(ctx, mel, batch, W.cfg.n_mels, t_mel, b.mel16, s))) return rc;
 
-    auto conv = [&](const VocConv& cv, const uint16_t* x, int T, float act_slope, uint16_t* y16, const float* res_in,
-                    float* res_out) -> int32_t {
+    const int res16 = voc_res16(ctx) ? 1 : 0;
+    auto conv = [&](const VocConv& cv, const uint16_t* x, int T, float act_slope, uint16_t* y16, const void* res_in,
+                    void* res_out, int act_in = 0) -> int32_t {
         ConvParams p{};
+        p.res16 = res16; p.act_in = act_in;
         p.x = x; p.w = cv.w; p.bias = cv.bias; p.B = batch; p.Tin = T; p.Ci = cv.Ci; p.Co = cv.Co; p.taps = cv.k;
         p.off0 = -((cv.k - 1) / 2) * cv.dil; p.dtap = cv.dil; p.phases = 1; p.q_count = T;
         p.out_mul = 1; p.out_add0 = 0; p.out_add_step = 0; p.Tout = T;
@@ -229,18 +238,26 @@ extern "C" int32_t asrfe_vocoder_forward(asrfe_ctx* ctx, const float* mel, int32
             p.x = b.a[0]; p.w = S.up_w; p.bias = S.up_b; p.B = batch; p.Tin = T; p.Ci = S.Ci; p.Co = S.Co; p.taps = S.k / S.u;
             p.off0 = 0; p.dtap = -1; p.phases = S.u; p.q_count = T + 1;
             p.out_mul = S.u; p.out_add0 = -((S.k - S.u) / 2); p.out_add_step = 1; p.Tout = Tout;
-            p.slope = slope; p.y16 = fused ? nullptr : b.a[1]; p.res_out = b.r[0];
+            p.slope = slope; p.y16 = (fused || res16) ? nullptr : b.a[1]; p.res_out = b.r[0]; p.res16 = res16;
             if ((rc = launch_conv_mfma(ctx, p, s))) return rc;
         }
         T = Tout;
         for (int j = 0; j < nrb; ++j) {
-            const float* xr = b.r[0];
+            const void* xr = b.r[0];
             const uint16_t* xa = b.a[1];
             for (int q = 0; q < 3; ++q) {
                 const bool last = q == 2;  // the block's output goes to its own buffer; nothing reads its activated copy
-                float* ro = last ? b.out[j] : b.r[1 + (q & 1)];
+                void* ro = last ? b.out[j] : b.r[1 + (q & 1)];
                 if (fused) {
-                    if ((rc = launch_conv_pair(ctx, xr, ro, S.c1[j * 3 + q], S.c2[j * 3 + q], batch, T, slope, s))) return rc;
+                    if ((rc = launch_conv_pair(ctx, xr, ro, res16, S.c1[j * 3 + q], S.c2[j * 3 + q], batch, T, slope, s))) return rc;
+                    xr = ro;
+                    continue;
+                }
+                if (res16) {
+                    // the 16-bit stream is its own operand: the first convolution activates it while staging, the second
+                    // adds it and stores the raw sum in the same type (10 bytes per element and pair instead of 16)
+                    if ((rc = conv(S.c1[j * 3 + q], static_cast<const uint16_t*>(xr), T, slope, b.a[0], nullptr, nullptr, 1))) return rc;
+                    if ((rc = conv(S.c2[j * 3 + q], b.a[0], T, slope, nullptr, xr, ro))) return rc;
                     xr = ro;
                     continue;
                 }
@@ -254,7 +271,7 @@ extern "C" int32_t asrfe_vocoder_forward(asrfe_ctx* ctx, const float* mel, int32
         // mean over the residual blocks, then the leaky ReLU in front of the next transposed convolution (or, with its
         // own slope, in front of the output convolution)
         const bool final_stage = i + 1 == W.stages.size();
-        if ((rc = launch_scale_act(ctx, b.out, nrb, 1.0f / static_cast<float>(nrb), final_stage ? W.cfg.final_slope : slope,
+        if ((rc = launch_scale_act(ctx, b.out, res16, nrb, 1.0f / static_cast<float>(nrb), final_stage ? W.cfg.final_slope : slope,
                                    static_cast<int64_t>(batch) * T * S.Co, b.a[0], s)))
             return rc;
     }

@@ -20,10 +20,14 @@ struct ConvParams {
     int phases, q_count;   // positions per phase
     int out_mul, out_add0, out_add_step;  // output time = q * out_mul + out_add0 + phase * out_add_step (outside [0, Tout): dropped)
     int Tout;
-    float slope;           // leaky ReLU applied to what y16 receives
+    float slope;           // leaky ReLU applied to what y16 receives (and, with act_in, to x while it is staged)
     uint16_t* y16;         // optional [B][Tout][Co]: lrelu(result)
-    const float* res_in;   // optional [B][Tout][Co] f32 added to the result
-    float* res_out;        // optional [B][Tout][Co] f32: the result
+    const void* res_in;    // optional [B][Tout][Co] added to the result: f32, or 16-bit with res16
+    void* res_out;         // optional [B][Tout][Co]: the result, f32, or rounded to 16-bit with res16
+    int res16;             // the residual stream is kept in the 16-bit operand type (fp16 contexts): res_in / res_out are
+                           // 16-bit arrays of the raw (not activated) values
+    int act_in;            // x holds raw values: the leaky ReLU in front of the convolution is applied while x is staged
+                           // (fp16 operands only)
     int ci_tile;           // input channels staged per pass (filled by launch_conv_mfma)
     int flags;             // timing experiments (ASRFE_VOC_ABLATE; read by a -DASRFE_VOC_TIMING build only, bit 16 by the launcher)
 };
@@ -49,13 +53,15 @@ int32_t launch_conv_mfma(asrfe_ctx* ctx, const ConvParams& p, hipStream_t s);
 // a residual pair (dilated convolution, plain convolution, both C -> C over k taps) as one launch on the f32 stream:
 // out = x + conv2(lrelu(conv1(lrelu(x)) + b1)) + b2; built for 32 and 64 channels (conv_pair_supported)
 bool conv_pair_supported(int C, int k, int dil);
-int32_t launch_conv_pair(asrfe_ctx* ctx, const float* x, float* out, const VocConv& c1, const VocConv& c2, int B, int T, float slope,
-                         hipStream_t s);
+// (res16: x and out are 16-bit arrays, see ConvParams)
+int32_t launch_conv_pair(asrfe_ctx* ctx, const void* x, void* out, int res16, const VocConv& c1, const VocConv& c2, int B, int T,
+                         float slope, hipStream_t s);
 int32_t prepare_conv(asrfe_ctx* ctx);  // per-device kernel attributes; called by asrfe_load_vocoder_weights
 // mel f32 [B][n_mels][T] -> 16-bit [B][T][n_mels]
 int32_t launch_mel_to_ntc(asrfe_ctx* ctx, const float* mel, int B, int n_mels, int T, uint16_t* out, hipStream_t s);
 // y16 = lrelu((a + b + ...) * scale, slope) over n_in arrays (at most 4) of n elements
-int32_t launch_scale_act(asrfe_ctx* ctx, const float* const* in, int n_in, float scale, float slope, int64_t n, uint16_t* y16,
+// (res16: the inputs are 16-bit arrays)
+int32_t launch_scale_act(asrfe_ctx* ctx, const void* const* in, int res16, int n_in, float scale, float slope, int64_t n, uint16_t* y16,
                          hipStream_t s);
 // wav[b][t] = tanh(bias + sum over (tap < 7, ci) w[tap][ci] x[b][t + tap - 3][ci])
 int32_t launch_conv_post(asrfe_ctx* ctx, const uint16_t* x, const float* w, const float* bias, int B, int T, int C,

@@ -14,6 +14,20 @@ __device__ __forceinline__ float from_elem(uint16_t u) {
     else return __uint_as_float(static_cast<uint32_t>(u) << 16);
 }
 __device__ __forceinline__ float lrelu(float v, float slope) { return v > 0.0f ? v : v * slope; }
+// leaky ReLU on eight packed fp16 values (0 < slope < 1: max(v, slope v)); the product is rounded to fp16, as the
+// activated copies are that the producers store otherwise
+template <bool F16>
+__device__ __forceinline__ uint4 lrelu_packed(uint4 v, float slope) {
+    if constexpr (F16) {
+        typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+        const h8 x = __builtin_bit_cast(h8, v);
+        const _Float16 s = static_cast<_Float16>(slope);
+        const h8 y = __builtin_elementwise_max(x, x * s);
+        return __builtin_bit_cast(uint4, y);
+    } else {
+        return v;  // (not used with bf16 operands: the launcher refuses act_in there)
+    }
+}
 }  // namespace
 
 // Convolution tile kernel.  A workgroup (4 waves) owns NC * 32 output channels x 4 * NP * 32 positions of one batch item
@@ -28,6 +42,10 @@ __device__ __forceinline__ float lrelu(float v, float slope) { return v > 0.0f ?
 //   ahead; one counted wait + barrier per group.  Every workgroup of a launch reads the same weight rows: fetched once
 //   per workgroup and far ahead, they arrive from L2 without the latency of a hot line showing up in the loop.
 //   Accumulators start from the residual (loaded while the activations are staged): the epilogue adds the bias and stores.
+//   In fp16 contexts the residual stream is itself kept in fp16 (ConvParams::res16): it is read as the accumulators'
+//   start, stored rounded, and doubles as the next convolution's operand, which applies the leaky ReLU while staging
+//   (ConvParams::act_in: packed fp16 max(v, slope v) on the 16-byte chunks in flight), so a convolution writes one
+//   16-bit array instead of an f32 one and an activated 16-bit copy.
 //   Per k-step (16 input channels of one tap) a wave issues NC * NP MFMAs on NC weight and NP activation fragments.
 // MFMA operand layout: lane (l31, h) holds 8 consecutive k = 8 consecutive input channels of one tap, of position l31
 // (A) and of weight row l31 (B); accumulator register 4 g + e is position 8 g + 4 h + e of output channel l31.
@@ -107,15 +125,26 @@ __global__ __launch_bounds__(256, OCC) void conv_tile_kernel(const ConvParams p)
     };
     {   // accumulators start from the residual (the bias is added when they are stored: nothing here depends on a
         // load, so all of them are in flight together and are waited for at the first MFMA)
-        const __amdgpu_buffer_rsrc_t res_rsrc = rsrc_of(p.res_in ? static_cast<const void*>(p.res_in) : p.bias, 4);
         const bool with_res = p.res_in && !(tflags & 8);
+        if (p.res16 && with_res) {
+            const __amdgpu_buffer_rsrc_t res_rsrc = rsrc_of(p.res_in, 2);
 #pragma unroll
-        for (int nc = 0; nc < NC; ++nc)
+            for (int nc = 0; nc < NC; ++nc)
 #pragma unroll
-            for (int np = 0; np < NP; ++np)
+                for (int np = 0; np < NP; ++np)
 #pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    acc[nc][np][r] = with_res ? __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(res_rsrc, off4(nc, np, r), 0, 0)) : 0.0f;
+                    for (int r = 0; r < 16; ++r)
+                        acc[nc][np][r] = from_elem<F16>(static_cast<uint16_t>(__builtin_amdgcn_raw_buffer_load_b16(res_rsrc, off4(nc, np, r) >> 1, 0, 0)));
+        } else {
+            const __amdgpu_buffer_rsrc_t res_rsrc = rsrc_of(p.res_in ? static_cast<const void*>(p.res_in) : p.bias, 4);
+#pragma unroll
+            for (int nc = 0; nc < NC; ++nc)
+#pragma unroll
+                for (int np = 0; np < NP; ++np)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        acc[nc][np][r] = with_res ? __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(res_rsrc, off4(nc, np, r), 0, 0)) : 0.0f;
+        }
     }
 
     // weight staging: instruction w + 4 i of a group (i < kInstrPerWave) moves ring rows kRowsPerInstr (w + 4 i) ...;
@@ -160,6 +189,10 @@ __global__ __launch_bounds__(256, OCC) void conv_tile_kernel(const ConvParams p)
                 v[u] = make_uint4(0, 0, 0, 0);
                 if (i < n_chunks && ti >= 0 && ti < p.Tin)
                     v[u] = *reinterpret_cast<const uint4*>(xitem + static_cast<int64_t>(ti) * p.Ci + ci0 + 8 * c);
+            }
+            if (p.act_in) {
+#pragma unroll
+                for (int u = 0; u < NSTG; ++u) v[u] = lrelu_packed<F16>(v[u], p.slope);
             }
 #pragma unroll
             for (int u = 0; u < NSTG; ++u)
@@ -213,7 +246,7 @@ __global__ __launch_bounds__(256, OCC) void conv_tile_kernel(const ConvParams p)
 
     // ---- epilogue: bias, stores (32 lanes = the 32 consecutive channels of one position)
     if (!((tflags & 1) && acc[0][0][0] != 12345.0f)) {
-        const __amdgpu_buffer_rsrc_t ro_rsrc = rsrc_of(p.res_out ? static_cast<const void*>(p.res_out) : p.bias, 4);
+        const __amdgpu_buffer_rsrc_t ro_rsrc = rsrc_of(p.res_out ? static_cast<const void*>(p.res_out) : p.bias, p.res16 ? 2 : 4);
         const __amdgpu_buffer_rsrc_t y_rsrc = rsrc_of(p.y16 ? static_cast<const void*>(p.y16) : p.bias, 2);
         float bv[NC];
 #pragma unroll
@@ -226,7 +259,10 @@ __global__ __launch_bounds__(256, OCC) void conv_tile_kernel(const ConvParams p)
                 for (int nc = 0; nc < NC; ++nc) {
                     const uint32_t o = off4(nc, np, r);
                     const float v = acc[nc][np][r] + bv[nc];
-                    if (p.res_out) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, v), ro_rsrc, o, 0, 0);
+                    if (p.res_out) {
+                        if (p.res16) __builtin_amdgcn_raw_buffer_store_b16(to_elem<F16>(v), ro_rsrc, o >> 1, 0, 0);
+                        else __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, v), ro_rsrc, o, 0, 0);
+                    }
                     if (p.y16) __builtin_amdgcn_raw_buffer_store_b16(to_elem<F16>(lrelu(v, p.slope)), y_rsrc, o >> 1, 0, 0);
                 }
     }
@@ -246,6 +282,9 @@ __global__ __launch_bounds__(256, OCC) void conv_tile_kernel(const ConvParams p)
 // traffic; run as two launches a pair moves 16 bytes per element (16-bit copy in, 16-bit intermediate out and in again,
 // f32 residual in, f32 and 16-bit results out), fused it moves 8: the f32 stream is read once (converted to the 16-bit
 // operand type, leaky ReLU applied, while it is staged) and written once; the intermediate never leaves the LDS.
+//   (With the residual stream in fp16, PairParams::res16, the pair moves 4 bytes per element: 16-byte chunks of x go
+//   straight to the LDS through the same packed leaky ReLU as the two-launch form's staging, the accumulators start from
+//   the 16-bit x and the result is stored rounded; the bits are again those of the two launches.)
 //   A workgroup (4 waves) owns M = 4 * NP * 32 positions of conv1's output, of which the inner P = M - (k - 1) are the
 //   positions of conv2's output it stores (conv2 needs (k - 1) / 2 rows of conv1 on either side; neighbouring tiles
 //   recompute those).  A1 = lrelu(x) rows [p0 - h2 - h1, ... + M + (k - 1) d), A2 = lrelu(conv1 + b1) rows
@@ -257,8 +296,9 @@ __global__ __launch_bounds__(256, OCC) void conv_tile_kernel(const ConvParams p)
 //   and more workgroups in different phases hide more of it (measured against 1 x 4 with two per CU).
 //   The arithmetic (operand rounding, accumulation order) is that of the two separate launches: results are identical.
 struct PairParams {
-    const float* x;       // [B][T][C] residual stream in
-    float* out;           // [B][T][C] residual stream out (a different buffer: tiles read their neighbours' rows of x)
+    const void* x;        // [B][T][C] residual stream in: f32, or the 16-bit operand type with res16
+    void* out;            // [B][T][C] residual stream out (a different buffer: tiles read their neighbours' rows of x)
+    int res16;
     const uint16_t* w1;   // [C][k * C]
     const float* b1;
     const uint16_t* w2;
@@ -299,8 +339,21 @@ __global__ __launch_bounds__(256, OCC) void conv_pair_kernel(const PairParams p)
     constexpr uint32_t row4 = C * 4u;
     const uint32_t lane_off4 = static_cast<uint32_t>(p0 + wave * (NP * 32) + 4 * h) * row4 + static_cast<uint32_t>(l31) * 4u;
     auto off4 = [&](int nc, int np, int r) { return lane_off4 + static_cast<uint32_t>(np * 32 + 8 * (r >> 2) + (r & 3)) * row4 + nc * 128; };
-    {
-        const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x) + item, 0, n_rows * C * 4, 0x00020000);
+    if (p.res16) {
+        const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<uint16_t*>(static_cast<const uint16_t*>(p.x)) + item, 0, n_rows * C * 2, 0x00020000);
+#pragma unroll
+        for (int nc = 0; nc < NC; ++nc)
+#pragma unroll
+            for (int np = 0; np < NP; ++np)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    acc2[nc][np][r] = from_elem<F16>(static_cast<uint16_t>(__builtin_amdgcn_raw_buffer_load_b16(x_rsrc, off4(nc, np, r) >> 1, 0, 0)));
+                    acc1[nc][np][r] = 0.0f;
+                }
+    } else {
+        const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<float*>(static_cast<const float*>(p.x)) + item, 0, n_rows * C * 4, 0x00020000);
 #pragma unroll
         for (int nc = 0; nc < NC; ++nc)
 #pragma unroll
@@ -332,8 +385,33 @@ __global__ __launch_bounds__(256, OCC) void conv_pair_kernel(const PairParams p)
     for (int i = 0; i < NSLOT - 1; ++i) issue(i);
 
     // ---- stage A1 = lrelu(x) rows [p0 - h2 - h1, + R1) as 16-bit, zero outside [0, T)
-    {
-        const float* xitem = p.x + item;
+    if (p.res16) {
+        // x is already in the operand type: 16-byte chunks straight through, the activation on the packed values (the
+        // arithmetic of the two-launch form's staging, so that both forms give the same bits)
+        const uint16_t* xitem = static_cast<const uint16_t*>(p.x) + item;
+        const int first = p0 - h2 - h1;
+        const int n_chunks = R1 * cpr;
+        constexpr int NST16 = 10;
+        for (int i0 = tid; i0 < n_chunks; i0 += NST16 * 256) {
+            uint4 v[NST16];
+            int dst[NST16];
+#pragma unroll
+            for (int u = 0; u < NST16; ++u) {
+                const int i = i0 + u * 256;
+                const int r = i / cpr, c = i - r * cpr;
+                const int ti = first + r;
+                dst[u] = i < n_chunks ? r * stride + c * 16 : -1;
+                v[u] = make_uint4(0, 0, 0, 0);
+                if (i < n_chunks && ti >= 0 && ti < p.T)
+                    v[u] = *reinterpret_cast<const uint4*>(xitem + static_cast<int64_t>(ti) * C + 8 * c);
+            }
+#pragma unroll
+            for (int u = 0; u < NST16; ++u)
+                if (dst[u] >= 0) *reinterpret_cast<uint4*>(xs + dst[u]) = lrelu_packed<F16>(v[u], p.slope);
+        }
+        if (tid == 0) *reinterpret_cast<uint4*>(xs + zero_at) = make_uint4(0, 0, 0, 0);
+    } else {
+        const float* xitem = static_cast<const float*>(p.x) + item;
         const int first = p0 - h2 - h1;
         const int n_chunks = R1 * cpr;
         for (int i0 = tid; i0 < n_chunks; i0 += NSTG * 256) {
@@ -438,19 +516,30 @@ __global__ __launch_bounds__(256, OCC) void conv_pair_kernel(const PairParams p)
     run(a2_at, 1, acc2);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the ring's last (unused) groups
 
-    // ---- epilogue: bias, f32 rows out (32 lanes = the 32 consecutive channels of one position)
+    // ---- epilogue: bias, rows out (32 lanes = the 32 consecutive channels of one position)
     {
-        const __amdgpu_buffer_rsrc_t o_rsrc = __builtin_amdgcn_make_buffer_rsrc(p.out + item, 0, n_rows * C * 4, 0x00020000);
         float bv[NC];
 #pragma unroll
         for (int nc = 0; nc < NC; ++nc) bv[nc] = p.b2[nc * 32 + l31];
+        if (p.res16) {
+            const __amdgpu_buffer_rsrc_t o_rsrc = __builtin_amdgcn_make_buffer_rsrc(static_cast<uint16_t*>(p.out) + item, 0, n_rows * C * 2, 0x00020000);
 #pragma unroll
-        for (int np = 0; np < NP; ++np)
+            for (int np = 0; np < NP; ++np)
 #pragma unroll
-            for (int r = 0; r < 16; ++r)
+                for (int r = 0; r < 16; ++r)
 #pragma unroll
-                for (int nc = 0; nc < NC; ++nc)
-                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, acc2[nc][np][r] + bv[nc]), o_rsrc, off4(nc, np, r), 0, 0);
+                    for (int nc = 0; nc < NC; ++nc)
+                        __builtin_amdgcn_raw_buffer_store_b16(to_elem<F16>(acc2[nc][np][r] + bv[nc]), o_rsrc, off4(nc, np, r) >> 1, 0, 0);
+        } else {
+            const __amdgpu_buffer_rsrc_t o_rsrc = __builtin_amdgcn_make_buffer_rsrc(static_cast<float*>(p.out) + item, 0, n_rows * C * 4, 0x00020000);
+#pragma unroll
+            for (int np = 0; np < NP; ++np)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+#pragma unroll
+                    for (int nc = 0; nc < NC; ++nc)
+                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, acc2[nc][np][r] + bv[nc]), o_rsrc, off4(nc, np, r), 0, 0);
+        }
     }
 }
 
@@ -478,6 +567,31 @@ __global__ __launch_bounds__(256) void scale_act_kernel(const ScaleActIn src, in
     }
     reinterpret_cast<uint2*>(y16)[i] = make_uint2(pack_elem2<F16>(lrelu(v.x * scale, slope), lrelu(v.y * scale, slope)),
                                                   pack_elem2<F16>(lrelu(v.z * scale, slope), lrelu(v.w * scale, slope)));
+}
+
+// the same from 16-bit inputs (the residual stream in the operand type): eight values per thread
+struct ScaleActIn16 { const uint16_t* in[4]; };
+template <bool F16>
+__global__ __launch_bounds__(256) void scale_act16_kernel(const ScaleActIn16 src, int n_in, float scale, float slope, int64_t n8,
+                                                          uint16_t* __restrict__ y16) {
+    saturate_fp16_conversions<F16>();
+    const int64_t i = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
+    if (i >= n8) return;
+    float acc[8];
+    {
+        const u16x8 t = reinterpret_cast<const u16x8*>(src.in[0])[i];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] = from_elem<F16>(t[e]);
+    }
+    for (int k = 1; k < n_in; ++k) {
+        const u16x8 t = reinterpret_cast<const u16x8*>(src.in[k])[i];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] += from_elem<F16>(t[e]);
+    }
+    u16x8 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = to_elem<F16>(lrelu(acc[e] * scale, slope));
+    reinterpret_cast<u16x8*>(y16)[i] = o;
 }
 
 template <bool F16>
@@ -568,6 +682,8 @@ int32_t launch_conv_mfma(asrfe_ctx* ctx, const ConvParams& pin, hipStream_t s) {
         return set_err(ctx, ASRFE_ERR_SHAPE, "vocoder convolution: input channels must be a multiple of 16, output channels of 32");
     if (static_cast<int64_t>(p.B) * p.phases > 65535) return set_err(ctx, ASRFE_ERR_SHAPE, "vocoder convolution: batch * stride too large");
     if (p.taps * p.Ci < 8) return set_err(ctx, ASRFE_ERR_SHAPE, "vocoder convolution: too few weights");
+    if ((p.res16 || p.act_in) && ctx->cfg.enc_compute_dtype != ASRFE_DT_F16)
+        return set_err(ctx, ASRFE_ERR_BAD_ARG, "vocoder convolution: the 16-bit residual stream goes with fp16 operands");
     // (output rows are addressed by 32-bit byte offsets inside an item, up to eight position tiles past its end)
     if ((static_cast<int64_t>(p.Tout) + 8192ll * p.out_mul) * p.Co * 4 >= (int64_t{1} << 31))
         return set_err(ctx, ASRFE_ERR_SHAPE, "vocoder convolution: one item's output must stay below 2 GiB");
@@ -625,15 +741,18 @@ bool conv_pair_supported(int C, int k, int dil) {
     return false;
 }
 
-int32_t launch_conv_pair(asrfe_ctx* ctx, const float* x, float* out, const VocConv& c1, const VocConv& c2, int B, int T, float slope,
-                         hipStream_t s) {
+int32_t launch_conv_pair(asrfe_ctx* ctx, const void* x, void* out, int res16, const VocConv& c1, const VocConv& c2, int B, int T,
+                         float slope, hipStream_t s) {
     if (B <= 0 || T <= 0) return ASRFE_OK;
     const int C = c1.Co;
     if (c1.Ci != C || c2.Ci != C || c2.Co != C || c2.k != c1.k || c2.dil != 1 || !conv_pair_supported(C, c1.k, c1.dil) || x == out)
         return set_err(ctx, ASRFE_ERR_SHAPE, "vocoder pair: not a residual pair this kernel is built for");
     if (static_cast<int64_t>(T + 1024) * C * 4 >= (int64_t{1} << 31) || B > 65535)
         return set_err(ctx, ASRFE_ERR_SHAPE, "vocoder pair: one item's rows must stay below 2 GiB, batch below 65536");
+    if (res16 && ctx->cfg.enc_compute_dtype != ASRFE_DT_F16)
+        return set_err(ctx, ASRFE_ERR_BAD_ARG, "vocoder pair: the 16-bit residual stream goes with fp16 operands");
     PairParams p{};
+    p.res16 = res16;
     p.x = x; p.out = out; p.w1 = c1.w; p.b1 = c1.bias; p.w2 = c2.w; p.b2 = c2.bias; p.T = T; p.k = c1.k; p.dil = c1.dil; p.slope = slope;
     const bool f16 = ctx->cfg.enc_compute_dtype == ASRFE_DT_F16;
     const int M = 256, P = M - (c1.k - 1);
@@ -659,12 +778,22 @@ int32_t launch_mel_to_ntc(asrfe_ctx* ctx, const float* mel, int B, int n_mels, i
     return ASRFE_OK;
 }
 
-int32_t launch_scale_act(asrfe_ctx* ctx, const float* const* in, int n_in, float scale, float slope, int64_t n, uint16_t* y16,
+int32_t launch_scale_act(asrfe_ctx* ctx, const void* const* in, int res16, int n_in, float scale, float slope, int64_t n, uint16_t* y16,
                          hipStream_t s) {
     if (n <= 0) return ASRFE_OK;
     if (n_in < 1 || n_in > 4) return set_err(ctx, ASRFE_ERR_BAD_ARG, "stage average: 1..4 inputs");
+    if (res16) {
+        ScaleActIn16 src16{};
+        for (int k = 0; k < n_in; ++k) src16.in[k] = static_cast<const uint16_t*>(in[k]);
+        const int64_t n8 = n / 8;  // (channel counts are multiples of 32)
+        const dim3 grid16(static_cast<unsigned>((n8 + 255) / 256));
+        if (ctx->cfg.enc_compute_dtype == ASRFE_DT_F16) hipLaunchKernelGGL(scale_act16_kernel<true>, grid16, dim3(256), 0, s, src16, n_in, scale, slope, n8, y16);
+        else hipLaunchKernelGGL(scale_act16_kernel<false>, grid16, dim3(256), 0, s, src16, n_in, scale, slope, n8, y16);
+        VOC_CHECK_LAUNCH("stage average");
+        return ASRFE_OK;
+    }
     ScaleActIn src{};
-    for (int k = 0; k < n_in; ++k) src.in[k] = in[k];
+    for (int k = 0; k < n_in; ++k) src.in[k] = static_cast<const float*>(in[k]);
     const int64_t n4 = n / 4;  // (channel counts are multiples of 32)
     const dim3 grid(static_cast<unsigned>((n4 + 255) / 256)), block(256);
     if (ctx->cfg.enc_compute_dtype == ASRFE_DT_F16) hipLaunchKernelGGL(scale_act_kernel<true>, grid, block, 0, s, src, n_in, scale, slope, n4, y16);
