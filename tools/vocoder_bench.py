@@ -19,7 +19,10 @@ def main():
     ap.add_argument("--batch", type=int, default=128)
     ap.add_argument("--frames", type=int, default=94)   # 1 s at 24 kHz / hop 256
     ap.add_argument("--iters", type=int, default=10)
+    ap.add_argument("--lib", default=None, help="path of another build of libasrfe.so (timing builds: ASRFE_VOC_ABLATE)")
     args = ap.parse_args()
+    if args.lib:
+        pkg._lib.LIB_PATH = os.path.abspath(args.lib)
     gen = HiFiGANGenerator(sample_rate=24000)
     gen.load_state_dict(vocoder_state_dict(seed=2))
     mel = torch.randn(args.batch, 80, args.frames, device="cuda")
