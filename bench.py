@@ -328,7 +328,8 @@ def main():
         torch.cuda.synchronize()
         try:
             graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
+            # (thread-local capture: a process group's watchdog thread may query its events while this thread captures)
+            with torch.cuda.graph(graph, capture_error_mode="thread_local"):
                 eng.run(pcm, lens)
             graph.replay()
             torch.cuda.synchronize()
