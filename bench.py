@@ -83,7 +83,8 @@ def hbm_traffic(kernel):
 def side_traffic(program):
     """HBM bytes per pass of a whole side program ("decoder", "vocoder": tools/profile_side.sh) from the same file."""
     d, _ = counter_profile()
-    k = None if d is None else d.get("side", {}).get(program)
+    from tools.buildtag import side_tag
+    k = None if d is None or d.get("side_tag") != side_tag() else d.get("side", {}).get(program)
     return None if k is None else k["fetch_bytes"] + k["write_bytes"]
 
 

@@ -338,8 +338,12 @@ int32_t asrfe_debug_gemm(asrfe_ctx* ctx, const void* a, int32_t lda, const void*
  * qkv [m][1536] = norm1(x_out) Wqkv^T + b_qkv in the compute dtype, as asrfe_encoder_forward has it do.
  * flags bit 9 (512): x is given in the order asrfe_encoder_forward keeps the residual stream in between two launches
  * of this kernel, and x_out is written in it when qkv is set (row-major otherwise; y must be NULL): buffers of whole
- * 128-row tiles, per 32-row group [tile 16][quad 4][h 2][row 32][4 floats] with the 4 floats = columns
- * 32 tile + 8 quad + 4 h .. + 3 of the row.  The other flag bits are timing experiments that produce wrong results. */
+ * 128-row tiles.  The order is that of the kernel form the context was created for.  Default (v_mfma_f32_16x16x32):
+ * per 32-row group [block 16][a 2][mh 2][q 4][c 16][4 floats] with the 4 floats = columns 32 block + 16 a + 4 q .. + 3 of
+ * row 16 mh + c; that form serves only calls with bit 9 set and y == NULL (others return ASRFE_ERR_BAD_ARG).
+ * ASRFE_MFMA16=0 (or a plan with a row-major stream) at asrfe_create selects the v_mfma_f32_32x32x16 form: per 32-row
+ * group [tile 16][quad 4][h 2][row 32][4 floats] with the 4 floats = columns 32 tile + 8 quad + 4 h .. + 3 of the row.
+ * The other flag bits are timing experiments that produce wrong results. */
 int32_t asrfe_debug_post_attn(asrfe_ctx* ctx, int32_t layer, const void* att, const void* fsmn, const float* x,
                               float* x_out, void* y, void* qkv, int32_t m, int32_t flags, void* stream);
 

@@ -119,6 +119,30 @@ def test_full_size_decoder(pkg, plan):
     assert torch.equal(cut["embeds"], full["embeds"][:, :n_cut])
 
 
+def test_rows_beyond_one_round_of_half_height_tiles(pkg):
+    """More than 16384 token rows: the products with 512 output columns then take full-height tiles, whose after-the-fact
+    LayerNorm gathers its row statistics in front of the epilogue instead of behind the main loop.  72 copies of four
+    utterances (288 x 64 = 18432 rows): every copy gives the logits of the four-utterance call (the same sums in the same
+    order whatever the tile height), and those meet the oracle."""
+    cfg = po.DecoderConfig(num_blocks=2, vocab_size=515)
+    sd = po.make_state_dict(cfg, seed=41)
+    head = make_head(pkg, cfg, sd, 0)
+    g = torch.Generator().manual_seed(42)
+    mem = torch.randn(4, 150, 512, generator=g)
+    lens = torch.tensor([150, 97, 1, 128], dtype=torch.int32)
+    check_against_oracle(head, cfg, sd, mem, lens, n_max=64)
+    small = head.forward(mem.cuda(), lens, n_max=64, return_logits=True)
+    big = head.forward(mem.repeat(72, 1, 1).cuda(), lens.repeat(72), n_max=64, return_logits=True)
+    torch.cuda.synchronize()
+    assert big["token_ids"].shape == (288, 64) and 288 * 64 > 16384
+    for c in (0, 35, 71):
+        assert torch.equal(big["token_num"][4 * c:4 * c + 4], small["token_num"])
+        assert torch.equal(big["token_ids"][4 * c:4 * c + 4], small["token_ids"])
+        for k in range(4):
+            n = int(small["token_num"][k])
+            assert float((big["logits"][4 * c + k, :n] - small["logits"][k, :n]).abs().max()) <= 1e-5
+
+
 @pytest.mark.parametrize("vocab", [515, 8404])
 def test_token_ids_without_logits_equal_those_with(pkg, vocab):
     """A caller that does not ask for the logits gets its ids from the vocabulary projection's own per-strip maxima

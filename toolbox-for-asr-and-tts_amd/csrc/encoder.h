@@ -63,7 +63,9 @@ struct FfnParams {
     float* x_out;          // [M][512]
     int tiled;             // x (and, with qkv, x_out) in the kernel's register order instead of row-major: per 32-row
                            // group 16 tiles x 4 quads of 64 lanes x 16 bytes, lane l + 32 h of (tile nt, quad g) holding
-                           // columns 32 nt + 8 g + 4 h .. + 3 of row l; the buffers then span whole 128-row tiles
+                           // columns 32 nt + 8 g + 4 h .. + 3 of row l (post_attn.hip), or lane 16 q + c of run 2 a + mh of
+                           // block nt holding columns 32 nt + 16 a + 4 q .. + 3 of row 16 mh + c (post_attn16.hip); the
+                           // buffers then span whole 128-row tiles
     const uint16_t* wstream;  // Wo, W1 and W2 as the kernel's piece stream (LayerWeights::w_stream)
     const float* bo;       // [512]
     const float* b1;       // [ff]

@@ -15,7 +15,7 @@ import os
 import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from tools.buildtag import ROOT, csrc_tag  # noqa: E402
+from tools.buildtag import ROOT, csrc_tag, side_tag  # noqa: E402
 
 # (the post-attention variant that also projects the next layer's q, k, v: 49 of a step's 50 launches)
 KERNELS = {"post_attn": "post_attn16_kernel<true, 2>", "attention": "attn_kernel", "gemm_qkv": "gemm_bf16_kernel"}
@@ -66,6 +66,7 @@ def main():
     if len(sys.argv) > 5:
         # tools/profile_side.sh: whole programs (decoder head, vocoder), 4 passes each; every asrfe kernel's launches added up
         out["side"] = {}
+        out["side_tag"] = side_tag()
         for prog in ("dec", "voc"):
             tot = {}
             for cname, suffix in (("FETCH_SIZE", "f"), ("WRITE_SIZE", "w")):
