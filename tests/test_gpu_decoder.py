@@ -130,8 +130,8 @@ def test_rows_beyond_one_round_of_half_height_tiles(pkg):
     g = torch.Generator().manual_seed(42)
     mem = torch.randn(4, 150, 512, generator=g)
     lens = torch.tensor([150, 97, 1, 128], dtype=torch.int32)
-    check_against_oracle(head, cfg, sd, mem, lens, n_max=64)
-    small = head.forward(mem.cuda(), lens, n_max=64, return_logits=True)
+    check_against_oracle(head, cfg, sd, mem, lens)
+    small = head.forward(mem.cuda(), lens, n_max=64, return_logits=True)  # (n_max truncates: the first 64 tokens)
     big = head.forward(mem.repeat(72, 1, 1).cuda(), lens.repeat(72), n_max=64, return_logits=True)
     torch.cuda.synchronize()
     assert big["token_ids"].shape == (288, 64) and 288 * 64 > 16384
@@ -140,7 +140,8 @@ def test_rows_beyond_one_round_of_half_height_tiles(pkg):
         assert torch.equal(big["token_ids"][4 * c:4 * c + 4], small["token_ids"])
         for k in range(4):
             n = int(small["token_num"][k])
-            assert float((big["logits"][4 * c + k, :n] - small["logits"][k, :n]).abs().max()) <= 1e-5
+            if n:
+                assert float((big["logits"][4 * c + k, :n] - small["logits"][k, :n]).abs().max()) <= 1e-5
 
 
 @pytest.mark.parametrize("vocab", [515, 8404])
