@@ -113,6 +113,39 @@ def test_bench_batch_64x30s_matches_oracle_fixture(pkg):
     assert np.max(np.abs(out3l - got)) <= ENC_TOL
 
 
+@pytest.mark.parametrize("plan", ["ASRFE_UNFUSED_FFN", "ASRFE_SEPARATE_QKV"])
+def test_two_streams_repeat_bit_for_bit_under_the_plans_with_a_gemm_per_layer(pkg, monkeypatch, plan):
+    """The plans that launch the general GEMM in every layer (four products per layer unfused, one with a separate QKV
+    projection), two chunks on two streams, 64 x 30 s: every repetition gives the same bits.  The GEMM refills a
+    half-tile of its LDS ring right behind a workgroup barrier, and its operands are then lines the previous kernel
+    has just written (hot in L2, back within a few hundred cycles): a fragment read left in flight across that barrier
+    shows as blocks of 8 to 32 rows that change from run to run (it did, several times per run of this test, before
+    the kernel drained its reads in front of the barrier)."""
+    from toolbox_for_asr_and_tts_amd.synth import bench_pcm, encoder_state_dict
+    from toolbox_for_asr_and_tts_amd import _lib
+    monkeypatch.setenv(plan, "1")
+    n_blocks = 16
+    sd = encoder_state_dict(num_blocks=n_blocks, seed=0)
+    cfg = _lib.default_config()
+    cfg.enc_num_blocks = n_blocks
+    pcm = dev(bench_pcm(64, SAMPLES, seed=1234))
+    lens = torch.full((64,), SAMPLES, dtype=torch.int32, device="cuda")
+    eng = pkg.AsrEngine(batch=64, max_samples=SAMPLES, cfg=cfg, state_dict=sd, n_streams=2)
+    first = eng.run(pcm, lens)[0].clone()
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(first).all())
+    for it in range(8):
+        again = eng.run(pcm, lens)[0]
+        torch.cuda.synchronize()
+        if not torch.equal(again, first):
+            utts = (again != first).any(dim=2).any(dim=1).nonzero().flatten().tolist()
+            raise AssertionError(f"{plan}: repetition {it} differs from the first run in utterances {utts}")
+    # one stream, same engine: the same bits (the plan is a property of the context, not of the stream count)
+    single = eng.run_single_stream(pcm, lens)[0]
+    torch.cuda.synchronize()
+    assert torch.equal(single, first)
+
+
 def test_fbank_256x30s(pkg):
     """asrfe_fbank on the fbank-only configuration (256 clips of 30 s): frame counts, finiteness, batch-position
     independence (clips 0, 128, 255 alone give the same bits) and oracle frames at the start, in the middle and at the

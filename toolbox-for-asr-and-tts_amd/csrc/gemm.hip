@@ -46,21 +46,25 @@ constexpr int kSlotBytes = 4 * kHalfBytes;   // A0 | A1 | B0 | B1
 constexpr int kRingBytes = 2 * kSlotBytes;   // 128 KiB
 constexpr int kGemmLds = kRingBytes + 8 * 4096;  // + one 4 KiB epilogue slab per wave = 160 KiB
 
-// End of a phase: this wave's loads for the next phase have landed, then all waves meet.  One asm statement,
-// so nothing is scheduled between the wait and the barrier.  The LDS-DMA loads are issued through inline
-// assembly (lds_dma.h), so the compiler keeps COUNTED lgkmcnt waits for the fragment reads: a fragment read
-// issued in one phase is waited for only where its MFMA needs it, not at the phase boundary.  A half-tile
-// is refilled after this barrier while reads of it issued just before the barrier may not have returned yet;
-// they are already queued in the LDS pipeline, which serves one wave's requests in order and receives the DMA
-// data only a global-memory round trip later.
+// End of a phase: this wave's loads for the next phase have landed and its own fragment reads have returned, then all
+// waves meet.  One asm statement, so nothing is scheduled between the wait and the barrier.  The lgkmcnt(0) is not
+// optional: the phase behind this barrier starts by refilling a half-tile that other waves read during the phase in
+// front of it (the rolling activation fragments, whose last read is issued right before the barrier).  A read that
+// is merely queued in the LDS pipeline when its wave reaches the barrier can still lose against the refill: when the
+// LDS is saturated (the half-height variant) and the DMA data comes from a hot L2 line (activations the previous
+// kernel has just written), the new data has been seen to land first, and the wave then multiplies part of K-tile
+// g + 2 into K-tile g.  With every wave's reads returned before it arrives, no read of a half-tile is left anywhere
+// when the first refill behind the barrier is issued.  (The reads outstanding at this point are the ones the next
+// phase's first MFMAs need anyway; the drain costs 1 to 2 % of a product.)  The LDS-DMA loads are issued through
+// inline assembly (lds_dma.h), so within a phase the compiler's waits for the fragment reads stay counted.
 // The five youngest half-tiles are ten loads at full height.  At half height an activation half-tile is one load and a
 // weight half-tile two, and the five youngest are, depending on the phase, three activation + two weight half-tiles (7
 // loads) or two + three (8): the wait uses 7 everywhere, which at the second kind of phase also waits for one load more
 // than needed.
 #define PHASE_SYNC(steady)                                                                         \
     do {                                                                                           \
-        if (steady) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(MS == 2 ? 10 : 7) : "memory"); \
-        else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");                        \
+        if (steady) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(MS == 2 ? 10 : 7) : "memory"); \
+        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");                        \
     } while (0)
 
 // 16-byte global store with a selectable cache policy: 0 plain, 1 non-temporal, 2 write-through (sc1)

@@ -11,8 +11,11 @@ namespace asrfe {
 // LDS as a flat access and, while one is pending, turns every wait it inserts into vmcnt(0) / lgkmcnt(0); hidden
 // from it, its own LDS-read waits stay counted.  The kernel orders these loads itself with counted
 // s_waitcnt vmcnt(N) (loads complete in issue order).
+// The s_nop is required: on this generation an LDS-DMA instruction that issues in the cycle after a scalar write of M0
+// may still read the previous M0 (the compiler's hazard recognizer puts the wait state into code it generates itself,
+// but does not look inside an inline-assembly block), and the load then lands at the previous load's LDS address.
 __device__ __forceinline__ void lds_dma16(const void* sbase, uint32_t voff, uint32_t lds_addr) {
-    asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(lds_addr), "v"(voff), "s"(sbase) : "memory");
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(lds_addr), "v"(voff), "s"(sbase) : "memory");
 }
 
 // LDS byte address of a pointer into a __shared__ array

@@ -31,7 +31,10 @@ def main():
     ap.add_argument("--check", action="store_true")
     ap.add_argument("--iters", type=int, default=40)
     ap.add_argument("--flags", type=int, nargs="*", default=[0, 1])
+    ap.add_argument("--lib", default=None, help="path of another build of libasrfe.so (A/B timing)")
     args = ap.parse_args()
+    if args.lib:
+        pkg._lib.LIB_PATH = os.path.abspath(args.lib)
     ctx = pkg.Context()
     lib = ctx.lib
     dev = "cuda"
