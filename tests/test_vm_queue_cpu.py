@@ -40,3 +40,19 @@ def test_output_projection_waits_of_the_16x16x32_kernel():
         assert cq.check(path, cq.KERNEL16, 32) == []
     finally:
         shutil.rmtree(os.path.dirname(path), ignore_errors=True)
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="needs hipcc to generate the kernels' assembly")
+@pytest.mark.parametrize("source", ["gemm.hip", "attention.hip", "post_attn.hip", "post_attn16.hip", "vocoder_kernels.hip"])
+def test_every_lds_dma_load_keeps_its_distance_from_the_m0_write(source):
+    """An LDS-DMA load takes its LDS address from M0, and on gfx9 it must not issue in the cycle after the scalar write
+    of M0 (the loads are inline assembly, so the compiler's hazard padding does not apply): in the generated assembly of
+    every kernel that uses them, the nearest M0 write in front of each load is a scalar move at least two instructions
+    away, with no label in between."""
+    from tools import check_vm_queue as cq
+
+    path = cq.generate_asm(source)
+    try:
+        assert cq.check_m0(path) == []
+    finally:
+        shutil.rmtree(os.path.dirname(path), ignore_errors=True)

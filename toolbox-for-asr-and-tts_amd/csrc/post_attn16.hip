@@ -233,6 +233,15 @@ __global__ __launch_bounds__(kFfnThreads) void post_attn16_kernel(const FfnParam
         const uint32_t dst = __builtin_amdgcn_readfirstlane(smem_base + R * kPieceBytes + wave * 1024);
         lds_dma16(cbase + R * kPieceBytes, wq[i], dst + i * 4096);
     };
+    // the same in two parts around a pair of MFMAs (which are the M0 wait state: no s_nop in the loop)
+    auto stage_quarter_m0 = [&](auto rc, int i) {
+        constexpr int R = decltype(rc)::value;
+        lds_dma_set_m0(__builtin_amdgcn_readfirstlane(smem_base + R * kPieceBytes + wave * 1024) + i * 4096);
+    };
+    auto stage_quarter_load = [&](auto rc, const char* cbase, int i) {
+        constexpr int R = decltype(rc)::value;
+        lds_dma16_at_m0(cbase + R * kPieceBytes, wq[i]);
+    };
     // chunk c of the layer's stream: 0..3 are Wo, 4 + j is hidden chunk j
     auto chunk_base = [&](int ch) { return wsrc + static_cast<int64_t>(ch) * (8 * kPieceBytes); };
     auto stage = [&](auto rc, const char* cbase) {
@@ -419,6 +428,9 @@ __global__ __launch_bounds__(kFfnThreads) void post_attn16_kernel(const FfnParam
                 }
                 static_for<8>([&](auto f) {
                     constexpr int F = decltype(f)::value;
+                    // (the first pass finds its piece 7 already requested by the prologue)
+                    constexpr bool STAGE = (F & 1) == 0 && !(R == 0 && FIRST && C == 0);
+                    if constexpr (STAGE) stage_quarter_m0(IC<(R + 7) & 7>{}, F >> 1);
                     mfma_agpr<F16>(oacc[8 * nq + F][0], wf[F], afrag[2 * ks + 1][0]);
                     mfma_agpr<F16>(oacc[8 * nq + F][1], wf[F], afrag[2 * ks + 1][1]);
                     if constexpr (C == 3 && R == 7) {
@@ -427,12 +439,7 @@ __global__ __launch_bounds__(kFfnThreads) void post_attn16_kernel(const FfnParam
                         wf[F] = frag2(IC<((R + 1) & 7)>{}, f);
                     }
                     if constexpr ((F & 1) == 0) {
-                        if constexpr (R == 0) {
-                            // (the first pass finds its piece 7 already requested by the prologue)
-                            if constexpr (!(FIRST && C == 0)) stage_quarter(IC<7>{}, cb0, F >> 1);
-                        } else {
-                            stage_quarter(IC<(R + 7) & 7>{}, cb1, F >> 1);
-                        }
+                        if constexpr (STAGE) stage_quarter_load(IC<(R + 7) & 7>{}, R == 0 ? cb0 : cb1, F >> 1);
                     } else if constexpr (XLOAD) {
                         xload(IC<XSET>{}, xtile_of(PI / 2 + 3), IC<(F >> 1)>{});
                     }
@@ -538,15 +545,15 @@ __global__ __launch_bounds__(kFfnThreads) void post_attn16_kernel(const FfnParam
         // over the MFMA gaps of the second half instead of being issued back to back.
         static_for<8>([&](auto f) {
             constexpr int F = decltype(f)::value;
+#if ASRFE_FFN_ABLATE & 2  // timing experiment: the feed-forward's weight pieces are not requested (wrong results)
+            constexpr bool STAGE = false;
+#else
+            constexpr bool STAGE = (F & 1) == 0 && (R == 0 || !LAST);
+#endif
+            if constexpr (STAGE) stage_quarter_m0(IC<(R + 7) & 7>{}, F >> 1);
             mma(rc, IC<F + 8>{});
             if constexpr (!((LAST || TO_PROJ) && R == 7)) wf[F] = frag(IC<((R + 1) & 7)>{}, f);
-            if constexpr ((F & 1) == 0) {
-#if ASRFE_FFN_ABLATE & 2  // timing experiment: the feed-forward's weight pieces are not requested (wrong results)
-                return;
-#endif
-                if constexpr (R == 0) stage_quarter(IC<7>{}, cb0, F >> 1);
-                else if constexpr (!LAST) stage_quarter(IC<(R + 7) & 7>{}, cb1, F >> 1);
-            }
+            if constexpr (STAGE) stage_quarter_load(IC<(R + 7) & 7>{}, R == 0 ? cb0 : cb1, F >> 1);
         });
     };
     auto chunk = [&](int j, auto lastc) {

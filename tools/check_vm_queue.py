@@ -119,6 +119,47 @@ def check(path, kernel=KERNEL, mp=16):
     return errors
 
 
+def check_m0(path):
+    """Every LDS-DMA load of every kernel in the assembly file: the nearest M0 write in front of it is a scalar move in
+    the same straight-line stretch, with at least one instruction between the two (on gfx9 an LDS-DMA instruction issued
+    in the cycle after a scalar M0 write may still see the old M0; the compiler pads code it generates itself, never an
+    inline-assembly block).  Returns a list of error strings."""
+    errors = []
+    kernel, last_m0, since = None, None, 0
+    n_dma = 0
+    for ln, l in enumerate(open(path).read().splitlines(), 1):
+        t = l.strip()
+        if not t or t.startswith(";") or t.startswith("."):
+            continue
+        if re.match(r"^[A-Za-z_.$][\w.$]*:", t):  # a label: control flow may join here
+            if not t.startswith(".LBB") and not t.startswith("BB"):
+                kernel = t[:-1]
+            last_m0 = None
+            continue
+        op = t.split()[0]
+        if op.startswith("s_cbranch") or op in ("s_branch", "s_endpgm", "s_setpc_b64", "s_swappc_b64"):
+            since += 1
+            continue
+        if "global_load_lds" in op or (op.startswith("buffer_load") and " lds" in t):
+            n_dma += 1
+            if last_m0 is None:
+                errors.append(f"{path}:{ln} ({kernel}): LDS-DMA load with no M0 write in its straight-line stretch")
+            elif since < 1:
+                errors.append(f"{path}:{ln} ({kernel}): LDS-DMA load directly behind the M0 write of line {last_m0}")
+            since += 1
+            continue
+        ops = t[len(op):].split(",")
+        if ops and ops[0].strip() == "m0" and not op.startswith(("s_cmp", "s_bitcmp")):
+            if op != "s_mov_b32":
+                errors.append(f"{path}:{ln} ({kernel}): M0 written by {op}")
+            last_m0, since = ln, 0
+            continue
+        since += 1
+    if n_dma == 0:
+        errors.append(f"{path}: no LDS-DMA load found")
+    return errors
+
+
 def main():
     errors = []
     if len(sys.argv) > 1:
