@@ -144,6 +144,48 @@ def test_rows_beyond_one_round_of_half_height_tiles(pkg):
                 assert float((big["logits"][4 * c + k, :n] - small["logits"][k, :n]).abs().max()) <= 1e-5
 
 
+def test_head_and_vocoder_side_by_side_repeat_bit_for_bit(pkg):
+    """The decoder head at the bench's shape (64 x 500 frames, 16 blocks, vocabulary 8404) on one stream while the vocoder
+    (128 x 94 frames) runs on another: every repetition of either gives the bits of its run alone.  The head's products
+    are the general GEMM on half-height tiles with operands the launch before has just written, the case in which a
+    fragment read left in flight across the GEMM's phase barrier once lost against the refill of its half-tile; a
+    second stream on the same chip is what made that visible in the encoder."""
+    from oracle import hifigan_oracle as ho
+    from toolbox_for_asr_and_tts_amd.vocoder import HiFiGANGenerator
+    cfg = po.DecoderConfig()
+    head = make_head(pkg, cfg, po.make_state_dict(cfg, seed=51), 0)
+    g = torch.Generator().manual_seed(52)
+    mem = (torch.randn(64, 500, 512, generator=g) * 0.7).cuda()
+    lens = torch.full((64,), 500, dtype=torch.int32)
+    vcfg = ho.HifiganConfig()
+    gen = HiFiGANGenerator(n_mels=vcfg.n_mels, initial_channel=vcfg.initial_channel, upsample_rates=vcfg.upsample_rates,
+                           upsample_kernels=vcfg.upsample_kernels, resblock_kernels=vcfg.resblock_kernels,
+                           resblock_dilations=vcfg.resblock_dilations, lrelu_slope=vcfg.lrelu_slope, final_slope=vcfg.final_slope)
+    gen.load_state_dict(ho.make_state_dict(vcfg, seed=53))
+    mel = torch.randn(128, 80, 94, generator=g).cuda()
+
+    def head_run():
+        r = head.forward(mem, lens, n_max=256, return_alphas=True)
+        return [r["token_ids"].clone(), r["token_num"].clone(), r["embeds"].clone(), r["alphas"].clone()]
+
+    want_head = head_run()
+    want_wav = gen.forward(mel).clone()
+    torch.cuda.synchronize()
+    assert int(want_head[1].sum()) > 0 and bool(torch.isfinite(want_wav).all())
+    sa, sb = torch.cuda.Stream(), torch.cuda.Stream()
+    for it in range(6):
+        sa.wait_stream(torch.cuda.current_stream())
+        sb.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(sa):
+            got_head = head_run()
+        with torch.cuda.stream(sb):
+            got_wav = gen.forward(mel).clone()
+        torch.cuda.synchronize()
+        for a, b in zip(got_head, want_head):
+            assert torch.equal(a, b), it
+        assert torch.equal(got_wav, want_wav), it
+
+
 @pytest.mark.parametrize("vocab", [515, 8404])
 def test_token_ids_without_logits_equal_those_with(pkg, vocab):
     """A caller that does not ask for the logits gets its ids from the vocabulary projection's own per-strip maxima
