@@ -112,13 +112,23 @@ def fbank_units():
 
 
 def cpu_model():
+    """Model name of the first CPU with its family / model / stepping numbers and clock (a virtualised host often
+    reports a bare vendor name: the numbers still identify the part)."""
+    want = {"model name": None, "cpu family": None, "model": None, "stepping": None, "cpu MHz": None}
     try:
         for line in open("/proc/cpuinfo"):
-            if line.startswith("model name"):
-                return line.split(":", 1)[1].strip()
+            k, _, v = line.partition(":")
+            k = k.strip()
+            if k in want and want[k] is None:
+                want[k] = v.strip()
+            if all(x is not None for x in want.values()):
+                break
     except OSError:
         pass
-    return "unknown"
+    if want["model name"] is None:
+        return "unknown"
+    extra = ", ".join(f"{k.replace('cpu ', '')} {want[k]}" for k in ("cpu family", "model", "stepping", "cpu MHz") if want[k])
+    return want["model name"] + (f" ({extra})" if extra else "")
 
 
 def gemm_flops(m, n, k):
