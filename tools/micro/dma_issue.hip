@@ -8,6 +8,8 @@
 //      register operand at all
 //   4  global_load_dwordx4 into registers and ds_write_b128 eight fragments later, two per sixteen fragments (no DMA;
 //      the wait for the load is part of the figure: two register sets do not cover the latency)
+//   5  only the global_load_dwordx4 of form 4 (destination registers pinned for the whole loop, never waited for
+//      inside an iteration), 6  only its ds_write_b128: the issue cost of the two halves of a register path
 // and form 1 behind every 4th (the post-attention kernel's rate) and every 8th fragment.
 // Prints cycles per fragment and checks that forms 1-3 delivered the right bytes.
 //   hipcc --offload-arch=gfx950 -O3 tools/micro/dma_issue.hip -o tools/micro/dma_issue && tools/micro/dma_issue
@@ -59,6 +61,9 @@ __global__ __launch_bounds__(256) void k(const _Float16* __restrict__ rnd, const
     u4v rs_tid = {static_cast<unsigned>(wa), (static_cast<unsigned>(wa >> 32) & 0xffffu) | (16u << 16), 0x7fffffffu, 0x00800000u};
     u4v held[2];
     held[0] = held[1] = u4v{0, 0, 0, 0};
+    u4v pin[8];  // forms 5, 6: destinations / sources that stay allocated over the whole loop (tied at every iteration's end)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) pin[j] = u4v{1u + j, 2u, 3u, 4u};
     long long t0 = __builtin_readcyclecounter();
     h8 wf[8];
     const int a0 = static_cast<int>(reinterpret_cast<uintptr_t>(base0)) + lane * 16;
@@ -79,6 +84,8 @@ __global__ __launch_bounds__(256) void k(const _Float16* __restrict__ rnd, const
                 if (FORM == 1) asm volatile("global_load_lds_dwordx4 %0, %1" ::"v"(voff + so), "s"(wsrc) : "memory");
                 if (FORM == 2) asm volatile("buffer_load_dwordx4 %0, %1, %2 offen lds" ::"v"(voff), "s"(rs_raw), "s"(so) : "memory");
                 if (FORM == 3) asm volatile("buffer_load_dwordx4 off, %0, %1 lds" ::"s"(rs_tid), "s"(so) : "memory");
+                if (FORM == 5) asm volatile("global_load_dwordx4 %0, %1, %2" : "+v"(pin[i >> 1]) : "v"(voff + so), "s"(wsrc) : "memory");
+                if (FORM == 6) asm volatile("ds_write_b128 %0, %1" ::"v"(static_cast<unsigned>(dst + voff)), "v"(pin[i >> 1]) : "memory");
                 if (FORM == 4) {
                     if (i == 0 || i == 8) {  // (two loads per iteration in this form: registers are the limit)
                         asm volatile("s_waitcnt vmcnt(1)" : "+v"(held[(i >> 3) & 1]) : : "memory");
@@ -89,13 +96,15 @@ __global__ __launch_bounds__(256) void k(const _Float16* __restrict__ rnd, const
             }
         }
         if (FORM >= 1 && FORM <= 3) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        if (FORM == 5 || FORM == 6)
+            asm volatile("s_waitcnt vmcnt(8)" : "+v"(pin[0]), "+v"(pin[1]), "+v"(pin[2]), "+v"(pin[3]), "+v"(pin[4]), "+v"(pin[5]), "+v"(pin[6]), "+v"(pin[7]) : : "memory");
     }
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     long long t1 = __builtin_readcyclecounter();
     float s = 0.0f;
 #pragma unroll
     for (int i = 0; i < 32; ++i) s += acc[i][0] + acc[i][3];
-    if (FORM >= 4) s += __builtin_bit_cast(float, held[0][0] ^ held[1][1]) * 0.0f;
+    if (FORM >= 4) s += __builtin_bit_cast(float, held[0][0] ^ held[1][1] ^ pin[0][0] ^ pin[7][3]) * 0.0f;
     __syncthreads();
     // the ring now holds the last iteration's eight 1 KiB loads of every wave (forms 1-3): sum of its words
     unsigned cs = 0;
@@ -175,6 +184,10 @@ int main() {
         run<1, 4>("1 every 4th fragment (the post-attention kernel's rate)", rnd, src, hsrc, cyc, sink, check);
         run<1, 8>("1 every 8th fragment", rnd, src, hsrc, cyc, sink, check);
         run<3, 4>("3 every 4th fragment", rnd, src, hsrc, cyc, sink, check);
+        run<5, 2>("5 + global_load_dwordx4 into registers only, every 2nd fragment", rnd, src, hsrc, cyc, sink, check);
+        run<5, 4>("5 every 4th fragment", rnd, src, hsrc, cyc, sink, check);
+        run<6, 2>("6 + ds_write_b128 only, every 2nd fragment", rnd, src, hsrc, cyc, sink, check);
+        run<6, 4>("6 every 4th fragment", rnd, src, hsrc, cyc, sink, check);
     }
     return 0;
 }
