@@ -332,11 +332,13 @@ def main():
 
     step = lambda: eng.run(pcm, lens)
     graph_replay = False
+    plain_out = None  # the output of one plain-launch step, to hold the replayed graph's output against
     if args.graph:
         # the step's ~105 launches on its two streams as one HIP graph: the same kernels on the same buffers, launched
         # by one call (the launch-bound part of a 12 ms step is about 1 %)
         eng.run(pcm, lens)
         torch.cuda.synchronize()
+        plain_out = eng.out.clone()
         try:
             graph = torch.cuda.CUDAGraph()
             # (thread-local capture: a process group's watchdog thread may query its events while this thread captures)
@@ -372,6 +374,9 @@ def main():
     else:
         global_batch = args.batch
     out_ok = bool(torch.isfinite(eng.out).all().item())
+    # what the last timed step left in the output buffer is, bit for bit, what a step of plain launches computes
+    replay_equals_plain = bool(torch.equal(eng.out, plain_out)) if (graph_replay and plain_out is not None) else None
+    del plain_out
 
     result = None
     if rank == 0:
@@ -402,6 +407,7 @@ def main():
                 "graph_replay": graph_replay,
             },
             "output_finite": out_ok,
+            "graph_replay_output_equals_plain_launches": replay_equals_plain,
             # what one rank has of the host: the step is launched from one thread, but a rank that shares a core with
             # another shows up as launch gaps at N = 8
             "host": {"cores_per_rank": len(os.sched_getaffinity(0)), "cpus_on_box": os.cpu_count(),
